@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline measurement on MI355X.
+
+Metric (BASELINE.json): Gnt/s encode+decode on 16 GiB random ACGT; fraction of the HBM
+roofline.  One "step" = one pass of the hot path over one batch: n_to_bits encode of the
+device-resident 16 GiB ASCII buffer (-> 4 GiB packed) followed by bits_to_n decode of the
+packed words (-> 16 GiB ASCII).  Inputs are generated on the device (counter-based ACGT
+generator, seed in the JSON) and are resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N --steps K --warmup W]                     (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W          (N>1, one rank per GPU)
+
+N>1: the global buffer (N x per-GPU size) is cut into contiguous chunks on word boundaries,
+rank r owns chunk r (cute_nucleotides_amd/sharding.py); there is no data-path collective --
+the process group is only used for the barrier and the max-over-ranks of the timing.  Weak
+scaling: per-GPU work is fixed.
+
+Rank 0 prints ONE JSON line.  `value` counts every nucleotide converted per second over all
+ranks (N encoded + N decoded per step and rank), inputs already in HBM.  `roofline` is for
+the n_to_bits encode kernel (the north-star target), `roofline_decode` for bits_to_n; both
+use ALGORITHMIC bytes (1.25 B/nt: encode 1 read + 0.25 written, decode 0.25 read + 1
+written) over the kernel's average duration measured live with HIP events on the
+launch stream.  `cpu_baseline` times the oracle's ports of the reference's fastest AVX2
+paths (n_to_bits_movemask / bits_to_n_shuffle) on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_NT = 1.25    # algorithmic bytes per nucleotide, each direction
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--log2-nt", type=int, default=34, help="per-GPU nucleotides = 2^k (default 34 = 16 GiB, the metric size)")
+    p.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    p.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline time budget (0 = skip)")
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(seconds):
+    """Time the oracle's x86 ports of the reference's best encoder/decoder on the host cores.
+    The oracle is used here only as the timed CPU baseline (kind 'port': the reference is Rust and
+    cannot be built in this image)."""
+    import threading
+
+    import numpy as np
+
+    from oracle import cnt_oracle as orc
+
+    orc.build()
+    if not orc.port_cpu_ok():
+        return {"value": None, "unit": "Gnt/s", "cores": 0, "kind": "port", "sample": "host CPU lacks AVX2/BMI2"}
+    L = orc.lib()
+    cores = os.cpu_count() or 1
+    n_len = 1 << 28  # 256 Mi nt sample, well past the host caches
+    n = orc.fill_random_acgt(n_len, 0x5EED)
+    words = n_len // 32
+    bits = np.empty(words, dtype=np.uint64)
+    out = orc._aligned_u8(n_len)
+
+    def run(fn_enc, fn_dec, threads, budget):
+        per = (n_len // threads) // 32 * 32
+        spans = [(k * per, n_len if k == threads - 1 else (k + 1) * per) for k in range(threads)]
+
+        def enc(lo, hi):
+            fn_enc(n.ctypes.data + lo, hi - lo, bits.ctypes.data + (lo // 32) * 8, (hi - lo + 31) // 32)
+
+        def dec(lo, hi):
+            fn_dec(bits.ctypes.data + (lo // 32) * 8, (hi - lo + 31) // 32, hi - lo, out.ctypes.data + lo)
+
+        def sweep(f):
+            t0 = time.perf_counter()
+            passes = 0
+            while True:
+                if threads == 1:
+                    f(*spans[0])
+                else:
+                    ts = [threading.Thread(target=f, args=s) for s in spans]
+                    [t.start() for t in ts]
+                    [t.join() for t in ts]
+                passes += 1
+                dt = time.perf_counter() - t0
+                if dt >= budget:
+                    return passes * n_len / dt / 1e9
+        return sweep(enc), sweep(dec)
+
+    q = max(seconds / 6.0, 0.5)
+    run(L.cnt_port_n_to_bits_movemask, L.cnt_port_bits_to_n_shuffle, cores, 0.0)  # untimed: first-touch the outputs
+    enc1, dec1 = run(L.cnt_port_n_to_bits_movemask, L.cnt_port_bits_to_n_shuffle, 1, q)
+    encN, decN = run(L.cnt_port_n_to_bits_movemask, L.cnt_port_bits_to_n_shuffle, cores, q)
+    assert bytes(out[: 1 << 16]) == bytes(n[: 1 << 16])  # the timed decode really round-trips
+    lut_nt = 1 << 24
+    t0 = time.perf_counter()
+    L.cnt_oracle_n_to_bits_lut(n.ctypes.data, lut_nt, bits.ctypes.data, lut_nt // 32)
+    lut_enc = lut_nt / (time.perf_counter() - t0) / 1e9
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    both = lambda e, d: 2.0 / (1.0 / e + 1.0 / d)  # nt converted per second over an encode pass + a decode pass
+    return {
+        "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
+        "sample": "256 Mi random ACGT nt; n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), "
+                  "%d threads over contiguous chunks, repeated for ~%.0f s; output preallocated" % (cores, seconds),
+        "encode_gnts": round(encN, 3), "decode_gnts": round(decN, 3),
+        "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3)},
+        "scalar_lut_encode_gnts_1thread": round(lut_enc, 3), "cpu_model": model,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import devutil, sharding
+
+    n_per = 1 << args.log2_nt
+    n_global = n_per * world
+    lo, hi = sharding.partition(n_global, world)[rank]  # contiguous chunk on a word boundary
+    n_len = hi - lo
+    words = cn.n_to_bits.words_for(n_len)
+
+    d_in = torch.empty(n_len, dtype=torch.uint8, device=dev)
+    d_packed = torch.empty(words, dtype=torch.int64, device=dev)
+    d_out = torch.empty(n_len, dtype=torch.uint8, device=dev)
+    devutil.fill_random_acgt(d_in, args.seed, first_nt=lo)
+    torch.cuda.synchronize()
+
+    def step():
+        cn.n_to_bits_dev(d_in, out=d_packed)
+        cn.bits_to_n_dev(d_packed, n_len, out=d_out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+
+    # per-kernel HIP events on the launch stream (torch's current stream == the stream the
+    # C ABI is handed), recorded inside the timed region
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        cn.n_to_bits_dev(d_in, out=d_packed)
+        ev[k][1].record()
+        cn.bits_to_n_dev(d_packed, n_len, out=d_out)
+        ev[k][2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    dec_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    verified = None
+    if not args.no_verify:
+        # outside the timed region: device-side round trip + the first chunk against the CPU oracle
+        import numpy as np
+
+        from oracle import cnt_oracle as orc
+
+        ok = devutil.count_mismatch(d_in, d_out) == 0
+        m = min(n_len, 1 << 22)
+        host_n = orc.fill_random_acgt(m, args.seed, first_nt=lo)
+        want = orc.n_to_bits_lut(host_n)
+        got = d_packed[: want.size].cpu().numpy().view(np.uint64)
+        ok = ok and bool(np.array_equal(got, want))
+        ok = ok and devutil.checksum_words(d_packed[: want.size], first_word=lo // 32) == orc.checksum_words(want, first_word=lo // 32)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
+
+    if rank == 0:
+        nt_per_step = 2 * n_global  # N encoded + N decoded, all ranks
+        value = nt_per_step * args.steps / elapsed / 1e9
+        enc_gbs = BYTES_PER_NT * n_len / (enc_ms * 1e-3) / 1e9
+        dec_gbs = BYTES_PER_NT * n_len / (dec_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and args.log2_nt == 34:
+            try:
+                traffic = json.load(open(tpath))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gnt/s encode+decode on 16 GiB random ACGT; % HBM read roofline at 1/8 GPU",
+            "value": round(value, 3), "unit": "Gnt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": "n_to_bits encode + bits_to_n decode of a device-resident uniform random ACGT buffer, "
+                            "%.3g GiB (2^%d nt) per GPU" % (n_per / 2**30, args.log2_nt),
+                "nt_per_gpu": n_per, "nt_per_step": nt_per_step, "seed": hex(args.seed),
+                "sharding": "contiguous chunks on word boundaries, no collective" if world > 1 else "single GPU",
+                "encode_variant": devutil.get_tuning("encode"), "decode_variant": devutil.get_tuning("decode"),
+            },
+            "encode_gnts_per_gpu": round(n_len / (enc_ms * 1e-3) / 1e9, 3),
+            "decode_gnts_per_gpu": round(n_len / (dec_ms * 1e-3) / 1e9, 3),
+            "roofline": {
+                "kernel": "n_to_bits (encode)", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4),
+                "traffic": (traffic or {}).get("encode_bytes_per_launch"),
+                "avg_kernel_ms": round(enc_ms, 4), "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
+                "read_only_view": {"achieved": round(n_len / (enc_ms * 1e-3) / 1e9, 1),
+                                   "frac": round(n_len / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            },
+            "roofline_decode": {
+                "kernel": "bits_to_n (decode)", "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                "traffic": (traffic or {}).get("decode_bytes_per_launch"),
+                "avg_kernel_ms": round(dec_ms, 4), "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
+            },
+            "verified": verified,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libcute_nt_hip.so -- every symbol include/cute_nt.h declares.
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the codec
+functions raises.  Nothing here (or anywhere in this package) touches oracle/.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcute_nt_hip.so")
+
+CNT_OK, CNT_EINVAL, CNT_ECAP, CNT_ELEN, CNT_ENODEV, CNT_ERANGE = 0, 1, 2, 3, 4, 5
+CNT_STRICT_LUT = 0x1
+
+_vp, _sz, _u64, _int, _uint = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint
+
+# name -> (restype, argtypes): the whole ABI, also used by tests/test_abi.py
+SIGNATURES = {
+    "cnt_strerror": (ctypes.c_char_p, [_int]),
+    "cnt_abi_version": (_int, []),
+    "cnt_words_for": (_sz, [_sz]),
+    "cnt_words2_for": (_sz, [_sz]),
+    "cnt_device_count": (_int, [ctypes.POINTER(_int)]),
+    "cnt_set_device": (_int, [_int]),
+    "cnt_get_device": (_int, [ctypes.POINTER(_int)]),
+    "cnt_shutdown": (_int, []),
+    "cnt_n_to_bits": (_int, [_vp, _sz, _vp, _sz]),
+    "cnt_n_to_bits_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
+    "cnt_bits_to_n": (_int, [_vp, _sz, _sz, _vp]),
+    "cnt_n_to_bits2": (_int, [_vp, _sz, _vp, _sz]),
+    "cnt_bits_to_n2": (_int, [_vp, _sz, _sz, _vp]),
+    "cnt_n_to_bits_sharded": (_int, [_vp, _sz, _vp, _sz, _int]),
+    "cnt_bits_to_n_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
+    "cnt_n_to_bits_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
+    "cnt_bits_to_n_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
+    "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
+    "cnt_bits_to_n2_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
+    "cnt_fill_random_acgt_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),
+    "cnt_fill_random_acgtn_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),
+    "cnt_checksum_words_dev": (_int, [_vp, _sz, _sz, _vp, _vp]),
+    "cnt_count_mismatch_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "cnt_set_tuning": (_int, [ctypes.c_char_p, _int]),
+    "cnt_get_tuning": (_int, [ctypes.c_char_p, ctypes.POINTER(_int)]),
+}
+
+_lib = None
+
+
+class CuteNtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("libcute_nt_hip: %s (status %d)" % (message, status))
+        self.status = status
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is not built -- no CPU fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -m cute_nucleotides_amd.build` "
+                "(or __graft_entry__.build()); this package has no CPU fallback" % LIB_PATH
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError here = ABI mismatch, fail loudly
+            f.restype = res
+            f.argtypes = args
+        if L.cnt_abi_version() != 1:
+            raise ImportError("libcute_nt_hip ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def strerror(status):
+    return lib().cnt_strerror(status).decode()
+
+
+def check(status):
+    """0 -> None; CNT_ELEN -> ValueError with the reference's panic text; else CuteNtError."""
+    if status == CNT_OK:
+        return
+    msg = strerror(status)
+    if status == CNT_ELEN:
+        raise ValueError(msg)  # "The length is greater than the number of nucleotides!"
+    raise CuteNtError(status, msg)

@@ -1,0 +1,622 @@
+// cute_nt.hip -- the C-ABI shim of libcute_nt_hip.so (include/cute_nt.h).
+//
+// Three tiers over the kernels in codec2_kernels.hpp / codec5_kernels.hpp:
+//   host-pointer tier   the drop-in for the reference's `&[u8] -> Vec<u64>`
+//                       functions: chunked, double-buffered H2D/kernel/D2H;
+//   sharded tier        contiguous chunks over the visible devices, one host
+//                       thread per device, no collective;
+//   device-pointer tier enqueue-only; what the roofline numbers measure.
+// No global mutable state apart from the tuning knobs (atomics); streams and
+// scratch are per calling thread, so the library is re-entrant like the
+// reference's pure functions.
+#include "../../include/cute_nt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <thread>
+#include <vector>
+
+#include "codec2_kernels.hpp"
+#include "codec5_kernels.hpp"
+#include "util_kernels.hpp"
+
+using namespace cnt;
+
+namespace {
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? CNT_OK : -(int)e; }
+
+#define CNT_TRY(expr)                      \
+    do {                                   \
+        int _rc = (expr);                  \
+        if (_rc != CNT_OK) return _rc;     \
+    } while (0)
+#define HIP_TRY(expr) CNT_TRY(hip_rc(expr))
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---- tuning knobs -------------------------------------------------------------
+// Variant ids (see DESIGN.md "kernel variants" for the measurements behind the
+// defaults).  value = kind*100 + unroll*2 + nt:
+//   kind 0 DIRECT (unroll 2,4,8)   kind 1 LDS (unroll 4,8)   kind 2 LANE (unroll 1,2)
+constexpr int V(int kind, int unroll, int nt) { return kind * 100 + unroll * 2 + nt; }
+std::atomic<int> g_encode_variant{V(0, 4, 0)};
+std::atomic<int> g_decode_variant{V(0, 4, 0)};
+std::atomic<int> g_encode_grid{0};  // 0 = one workgroup per tile; >0 = cap, grid-stride over tiles
+std::atomic<int> g_decode_grid{0};
+
+// ---- launch helpers -------------------------------------------------------------
+inline unsigned grid_for(uint64_t n_tiles, int cap) {
+    uint64_t g = n_tiles;
+    if (cap > 0 && g > (uint64_t)cap) g = (uint64_t)cap;
+    if (g > 0x7FFFFFFFull) g = 0x7FFFFFFFull;
+    return (unsigned)g;
+}
+
+inline unsigned generic_grid(uint64_t items) {
+    uint64_t b = (items + kBlock - 1) / kBlock;
+    return (unsigned)std::min<uint64_t>(std::max<uint64_t>(b, 1), 1u << 16);
+}
+
+struct EncodePlan {
+    uint64_t tile_nt;  // nucleotides per workgroup tile
+};
+
+template <bool STRICT>
+int launch_encode_main(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_nt) {
+    const int cap = g_encode_grid.load(std::memory_order_relaxed);
+    const u32x4* in = static_cast<const u32x4*>(d_n);
+#define ENC_DIRECT(U, NT)                                                                              \
+    case V(0, U, NT): {                                                                                \
+        const uint64_t tile = (uint64_t)kBlock * U * 16, nt = n_len / tile;                            \
+        if (nt) hipLaunchKernelGGL((n_to_bits_direct<U, NT, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in, \
+                                   static_cast<uint32_t*>(d_out), nt);                                 \
+        *done_nt = nt * tile;                                                                          \
+        break;                                                                                         \
+    }
+#define ENC_LDS(U, NT)                                                                                 \
+    case V(1, U, NT): {                                                                                \
+        const uint64_t tile = (uint64_t)kBlock * U * 16, nt = n_len / tile;                            \
+        if (nt) hipLaunchKernelGGL((n_to_bits_lds<U, NT, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,    \
+                                   static_cast<u32x4*>(d_out), nt);                                    \
+        *done_nt = nt * tile;                                                                          \
+        break;                                                                                         \
+    }
+#define ENC_LANE(R, NT)                                                                                \
+    case V(2, R, NT): {                                                                                \
+        const uint64_t tile = (uint64_t)kBlock * R * 64, nt = n_len / tile;                            \
+        if (nt) hipLaunchKernelGGL((n_to_bits_lane<R, NT, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,   \
+                                   static_cast<u32x4*>(d_out), nt);                                    \
+        *done_nt = nt * tile;                                                                          \
+        break;                                                                                         \
+    }
+    switch (variant) {
+        ENC_DIRECT(2, 0) ENC_DIRECT(2, 1) ENC_DIRECT(4, 0) ENC_DIRECT(4, 1) ENC_DIRECT(8, 0) ENC_DIRECT(8, 1)
+        ENC_LDS(4, 0) ENC_LDS(4, 1) ENC_LDS(8, 0) ENC_LDS(8, 1)
+        ENC_LANE(1, 0) ENC_LANE(1, 1) ENC_LANE(2, 0) ENC_LANE(2, 1)
+        default: return CNT_EINVAL;
+    }
+#undef ENC_DIRECT
+#undef ENC_LDS
+#undef ENC_LANE
+    return hip_rc(hipGetLastError());
+}
+
+int launch_decode_main(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_nt) {
+    const int cap = g_decode_grid.load(std::memory_order_relaxed);
+    u32x4* out = static_cast<u32x4*>(d_out);
+#define DEC_DIRECT(U, NT)                                                                              \
+    case V(0, U, NT): {                                                                                \
+        const uint64_t tile = (uint64_t)kBlock * U * 16, nt = len / tile;                              \
+        if (nt) hipLaunchKernelGGL((bits_to_n_direct<U, NT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,            \
+                                   static_cast<const uint32_t*>(d_bits), out, nt);                     \
+        *done_nt = nt * tile;                                                                          \
+        break;                                                                                         \
+    }
+#define DEC_LDS(Vv, NT)                                                                                \
+    case V(1, Vv, NT): {                                                                               \
+        const uint64_t tile = (uint64_t)kBlock * Vv * 64, nt = len / tile;                             \
+        if (nt) hipLaunchKernelGGL((bits_to_n_lds<Vv, NT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
+                                   static_cast<const u32x4*>(d_bits), out, nt);                        \
+        *done_nt = nt * tile;                                                                          \
+        break;                                                                                         \
+    }
+#define DEC_LANE(R, NT)                                                                                \
+    case V(2, R, NT): {                                                                                \
+        const uint64_t tile = (uint64_t)kBlock * R * 64, nt = len / tile;                              \
+        if (nt) hipLaunchKernelGGL((bits_to_n_lane<R, NT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
+                                   static_cast<const u32x4*>(d_bits), out, nt);                        \
+        *done_nt = nt * tile;                                                                          \
+        break;                                                                                         \
+    }
+    switch (variant) {
+        DEC_DIRECT(2, 0) DEC_DIRECT(2, 1) DEC_DIRECT(4, 0) DEC_DIRECT(4, 1) DEC_DIRECT(8, 0) DEC_DIRECT(8, 1)
+        DEC_LDS(1, 0) DEC_LDS(1, 1) DEC_LDS(2, 0) DEC_LDS(2, 1)
+        DEC_LANE(1, 0) DEC_LANE(1, 1) DEC_LANE(2, 0) DEC_LANE(2, 1)
+        default: return CNT_EINVAL;
+    }
+#undef DEC_DIRECT
+#undef DEC_LDS
+#undef DEC_LANE
+    return hip_rc(hipGetLastError());
+}
+
+// ---- per-thread device context (stream + grow-only scratch) ----------------------
+struct DevCtx {
+    int device = -1;
+    hipStream_t stream[2] = {nullptr, nullptr};
+    void* d_in[2] = {nullptr, nullptr};
+    void* d_out[2] = {nullptr, nullptr};
+    size_t cap_in = 0, cap_out = 0;
+
+    int ensure(size_t need_in, size_t need_out) {
+        for (int i = 0; i < 2; ++i)
+            if (!stream[i]) HIP_TRY(hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking));
+        if (need_in > cap_in) {
+            for (int i = 0; i < 2; ++i) {
+                if (d_in[i]) HIP_TRY(hipFree(d_in[i]));
+                d_in[i] = nullptr;
+                HIP_TRY(hipMalloc(&d_in[i], need_in));
+            }
+            cap_in = need_in;
+        }
+        if (need_out > cap_out) {
+            for (int i = 0; i < 2; ++i) {
+                if (d_out[i]) HIP_TRY(hipFree(d_out[i]));
+                d_out[i] = nullptr;
+                HIP_TRY(hipMalloc(&d_out[i], need_out));
+            }
+            cap_out = need_out;
+        }
+        return CNT_OK;
+    }
+    void release() {
+        if (device < 0) return;
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (hipSetDevice(device) == hipSuccess) {
+            for (int i = 0; i < 2; ++i) {
+                if (stream[i]) (void)hipStreamDestroy(stream[i]);
+                if (d_in[i]) (void)hipFree(d_in[i]);
+                if (d_out[i]) (void)hipFree(d_out[i]);
+                stream[i] = nullptr;
+                d_in[i] = d_out[i] = nullptr;
+            }
+        }
+        cap_in = cap_out = 0;
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct ThreadCtx {
+    std::map<int, DevCtx> per_device;
+    ~ThreadCtx() {
+        for (auto& kv : per_device) kv.second.release();
+    }
+    int get(DevCtx** out) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e == hipErrorNoDevice ? CNT_ENODEV : hip_rc(e);
+        DevCtx& c = per_device[dev];
+        c.device = dev;
+        *out = &c;
+        return CNT_OK;
+    }
+};
+thread_local ThreadCtx t_ctx;
+
+// Host-tier chunking: 64 Mi nucleotides per chunk keeps the scratch at
+// 2 x (64 MiB + 16 MiB) per thread while each chunk is ~1 ms of PCIe time.
+constexpr size_t kChunkNt = (size_t)64 << 20;  // multiple of 32 and of 27*... (see below for codec5)
+constexpr size_t kChunkNt5 = (size_t)27 * 2 << 20;  // 27-nt words: 2 Mi words per chunk
+
+// ---- device-tier bodies (shared by every tier) ------------------------------------
+int encode_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, hipStream_t s) {
+    const size_t words = cnt_words_for(n_len);
+    if (out_words < words) return CNT_ECAP;
+    if (flags & ~CNT_STRICT_LUT) return CNT_EINVAL;
+    if (n_len == 0) return CNT_OK;
+    if (!d_n || !d_out || !aligned(d_out, 8)) return CNT_EINVAL;
+    const bool strict = (flags & CNT_STRICT_LUT) != 0;
+    uint64_t done_nt = 0;
+    if (aligned(d_n, 16) && aligned(d_out, 16)) {
+        const int v = g_encode_variant.load(std::memory_order_relaxed);
+        CNT_TRY(strict ? launch_encode_main<true>(v, d_n, d_out, n_len, s, &done_nt)
+                       : launch_encode_main<false>(v, d_n, d_out, n_len, s, &done_nt));
+    }
+    if (done_nt < n_len) {
+        const uint64_t first_word = done_nt >> 5;
+        const unsigned g = generic_grid(words - first_word);
+        if (strict)
+            hipLaunchKernelGGL((n_to_bits_generic<true>), dim3(g), dim3(kBlock), 0, s, static_cast<const uint8_t*>(d_n),
+                               (uint64_t)n_len, static_cast<uint64_t*>(d_out), first_word, (uint64_t)words);
+        else
+            hipLaunchKernelGGL((n_to_bits_generic<false>), dim3(g), dim3(kBlock), 0, s, static_cast<const uint8_t*>(d_n),
+                               (uint64_t)n_len, static_cast<uint64_t*>(d_out), first_word, (uint64_t)words);
+        HIP_TRY(hipGetLastError());
+    }
+    return CNT_OK;
+}
+
+int decode_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, hipStream_t s) {
+    if (len > (words << 5) || (words > (SIZE_MAX >> 5))) return CNT_ELEN;
+    if (flags) return CNT_EINVAL;
+    if (len == 0) return CNT_OK;
+    if (!d_bits || !d_out || !aligned(d_bits, 8)) return CNT_EINVAL;
+    const size_t used_words = cnt_words_for(len);
+    uint64_t done_nt = 0;
+    if (aligned(d_bits, 16) && aligned(d_out, 16))
+        CNT_TRY(launch_decode_main(g_decode_variant.load(std::memory_order_relaxed), d_bits, d_out, len, s, &done_nt));
+    if (done_nt < len) {
+        const uint64_t first_word = done_nt >> 5;
+        hipLaunchKernelGGL(bits_to_n_generic, dim3(generic_grid(used_words - first_word)), dim3(kBlock), 0, s,
+                           static_cast<const uint64_t*>(d_bits), (uint64_t)len, static_cast<uint8_t*>(d_out), first_word,
+                           (uint64_t)used_words);
+        HIP_TRY(hipGetLastError());
+    }
+    return CNT_OK;
+}
+
+int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, hipStream_t s) {
+    const size_t words = cnt_words2_for(n_len);
+    if (out_words < words) return CNT_ECAP;
+    if (flags & ~CNT_STRICT_LUT) return CNT_EINVAL;
+    if (n_len == 0) return CNT_OK;
+    if (!d_n || !d_out || !aligned(d_out, 8)) return CNT_EINVAL;
+    const bool strict = (flags & CNT_STRICT_LUT) != 0;
+    uint64_t done_words = 0;
+    if (aligned(d_n, 16)) {
+        const uint64_t n_tiles = n_len / kTileBytes5;
+        if (n_tiles) {
+            const unsigned g = grid_for(n_tiles, g_encode_grid.load(std::memory_order_relaxed));
+            if (strict)
+                hipLaunchKernelGGL((n_to_bits2_tiled<true>), dim3(g), dim3(kBlock), 0, s, static_cast<const u32x4*>(d_n),
+                                   static_cast<uint64_t*>(d_out), n_tiles);
+            else
+                hipLaunchKernelGGL((n_to_bits2_tiled<false>), dim3(g), dim3(kBlock), 0, s, static_cast<const u32x4*>(d_n),
+                                   static_cast<uint64_t*>(d_out), n_tiles);
+            HIP_TRY(hipGetLastError());
+            done_words = n_tiles * kWords5;
+        }
+    }
+    if (done_words < words) {
+        const unsigned g = generic_grid(words - done_words);
+        if (strict)
+            hipLaunchKernelGGL((n_to_bits2_generic<true>), dim3(g), dim3(kBlock), 0, s, static_cast<const uint8_t*>(d_n),
+                               (uint64_t)n_len, static_cast<uint64_t*>(d_out), done_words, (uint64_t)words);
+        else
+            hipLaunchKernelGGL((n_to_bits2_generic<false>), dim3(g), dim3(kBlock), 0, s, static_cast<const uint8_t*>(d_n),
+                               (uint64_t)n_len, static_cast<uint64_t*>(d_out), done_words, (uint64_t)words);
+        HIP_TRY(hipGetLastError());
+    }
+    return CNT_OK;
+}
+
+int decode2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, hipStream_t s) {
+    if (words > SIZE_MAX / 27 || len > words * 27) return CNT_ELEN;
+    if (flags) return CNT_EINVAL;
+    if (len == 0) return CNT_OK;
+    if (!d_bits || !d_out || !aligned(d_bits, 8)) return CNT_EINVAL;
+    const size_t used_words = cnt_words2_for(len);
+    uint64_t done_words = 0;
+    if (aligned(d_out, 16)) {
+        const uint64_t n_tiles = len / kTileBytes5;
+        if (n_tiles) {
+            hipLaunchKernelGGL(bits_to_n2_tiled, dim3(grid_for(n_tiles, g_decode_grid.load(std::memory_order_relaxed))),
+                               dim3(kBlock), 0, s, static_cast<const uint64_t*>(d_bits), static_cast<u32x4*>(d_out),
+                               n_tiles);
+            HIP_TRY(hipGetLastError());
+            done_words = n_tiles * kWords5;
+        }
+    }
+    if (done_words < used_words) {
+        hipLaunchKernelGGL(bits_to_n2_generic, dim3(generic_grid(used_words - done_words)), dim3(kBlock), 0, s,
+                           static_cast<const uint64_t*>(d_bits), (uint64_t)len, static_cast<uint8_t*>(d_out), done_words,
+                           (uint64_t)used_words);
+        HIP_TRY(hipGetLastError());
+    }
+    return CNT_OK;
+}
+
+// ---- host tier: chunked double-buffered pipeline ------------------------------------
+// unit_nt: nucleotides per packed word (32 or 27); chunk_nt a multiple of it.
+typedef int (*enc_fn)(const void*, size_t, void*, size_t, unsigned, hipStream_t);
+typedef int (*dec_fn)(const void*, size_t, size_t, void*, unsigned, hipStream_t);
+
+int host_encode(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags, size_t unit_nt,
+                size_t chunk_nt, enc_fn fn) {
+    const size_t words = (n_len + unit_nt - 1) / unit_nt;
+    if (out_words < words) return CNT_ECAP;
+    if (flags & ~CNT_STRICT_LUT) return CNT_EINVAL;
+    if (n_len == 0) return CNT_OK;  // empty in -> empty out, no zero-size allocation (SURVEY 8a iv)
+    if (!n || !out) return CNT_EINVAL;
+    DevCtx* c = nullptr;
+    CNT_TRY(t_ctx.get(&c));
+    const size_t chunk = std::min(chunk_nt, (n_len + unit_nt - 1) / unit_nt * unit_nt);
+    CNT_TRY(c->ensure(chunk, chunk / unit_nt * 8));
+    size_t off = 0;
+    int slot = 0, rc = CNT_OK;
+    while (off < n_len && rc == CNT_OK) {
+        const size_t m = std::min(chunk, n_len - off);
+        const size_t w = (m + unit_nt - 1) / unit_nt;
+        hipStream_t s = c->stream[slot];
+        rc = hip_rc(hipStreamSynchronize(s));  // slot's previous D2H done before its buffers are reused
+        if (rc == CNT_OK) rc = hip_rc(hipMemcpyAsync(c->d_in[slot], n + off, m, hipMemcpyHostToDevice, s));
+        if (rc == CNT_OK) rc = fn(c->d_in[slot], m, c->d_out[slot], w, flags, s);
+        if (rc == CNT_OK)
+            rc = hip_rc(hipMemcpyAsync(out + off / unit_nt, c->d_out[slot], w * 8, hipMemcpyDeviceToHost, s));
+        off += m;
+        slot ^= 1;
+    }
+    for (int i = 0; i < 2; ++i) {
+        int r2 = hip_rc(hipStreamSynchronize(c->stream[i]));
+        if (rc == CNT_OK) rc = r2;
+    }
+    return rc;
+}
+
+int host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, size_t unit_nt, size_t chunk_nt,
+                dec_fn fn) {
+    if (words > SIZE_MAX / unit_nt || len > words * unit_nt) return CNT_ELEN;
+    if (len == 0) return CNT_OK;
+    if (!bits || !out) return CNT_EINVAL;
+    DevCtx* c = nullptr;
+    CNT_TRY(t_ctx.get(&c));
+    const size_t chunk = std::min(chunk_nt, (len + unit_nt - 1) / unit_nt * unit_nt);
+    // +32: the reference's SIMD decoders may store whole 32-B blocks; ours never
+    // writes past `len`, the slack only keeps device stores inside the scratch.
+    CNT_TRY(c->ensure(chunk / unit_nt * 8, chunk + 32));
+    size_t off = 0;
+    int slot = 0, rc = CNT_OK;
+    while (off < len && rc == CNT_OK) {
+        const size_t m = std::min(chunk, len - off);
+        const size_t w = (m + unit_nt - 1) / unit_nt;
+        hipStream_t s = c->stream[slot];
+        rc = hip_rc(hipStreamSynchronize(s));
+        if (rc == CNT_OK)
+            rc = hip_rc(hipMemcpyAsync(c->d_in[slot], bits + off / unit_nt, w * 8, hipMemcpyHostToDevice, s));
+        if (rc == CNT_OK) rc = fn(c->d_in[slot], w, m, c->d_out[slot], 0, s);
+        if (rc == CNT_OK) rc = hip_rc(hipMemcpyAsync(out + off, c->d_out[slot], m, hipMemcpyDeviceToHost, s));
+        off += m;
+        slot ^= 1;
+    }
+    for (int i = 0; i < 2; ++i) {
+        int r2 = hip_rc(hipStreamSynchronize(c->stream[i]));
+        if (rc == CNT_OK) rc = r2;
+    }
+    return rc;
+}
+
+int resolve_ndev(int ndev, int* out) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return CNT_ENODEV;
+    if (ndev <= 0) ndev = count;
+    if (ndev > count) return CNT_ENODEV;
+    *out = ndev;
+    return CNT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+// exported C ABI
+// =====================================================================================
+extern "C" {
+
+const char* cnt_strerror(int status) {
+    switch (status) {
+        case CNT_OK: return "ok";
+        case CNT_EINVAL: return "invalid argument (null pointer with non-zero size, unknown flag, bad alignment of a word pointer)";
+        case CNT_ECAP: return "output capacity too small";
+        case CNT_ELEN: return "The length is greater than the number of nucleotides!";  // n_to_bits.rs:53
+        case CNT_ENODEV: return "no such HIP device";
+        case CNT_ERANGE: return "shard offset is not on a word boundary";
+        default: break;
+    }
+    if (status < 0) return hipGetErrorString((hipError_t)(-status));
+    return "unknown status";
+}
+
+int cnt_abi_version(void) { return CNT_ABI_VERSION; }
+
+size_t cnt_words_for(size_t n_len) { return (n_len >> 5) + ((n_len & 31) ? 1 : 0); }
+size_t cnt_words2_for(size_t n_len) { return n_len / 27 + ((n_len % 27) ? 1 : 0); }
+
+int cnt_device_count(int* count) {
+    if (!count) return CNT_EINVAL;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) {
+        *count = 0;
+        return CNT_OK;
+    }
+    return hip_rc(e);
+}
+
+int cnt_set_device(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CNT_ENODEV;
+    return hip_rc(hipSetDevice(device));
+}
+
+int cnt_get_device(int* device) {
+    if (!device) return CNT_EINVAL;
+    return hip_rc(hipGetDevice(device));
+}
+
+int cnt_shutdown(void) {
+    for (auto& kv : t_ctx.per_device) kv.second.release();
+    t_ctx.per_device.clear();
+    return CNT_OK;
+}
+
+// ---- host tier ----------------------------------------------------------------------
+int cnt_n_to_bits_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags) {
+    return host_encode(n, n_len, out, out_words, flags, 32, kChunkNt, encode_dev);
+}
+int cnt_n_to_bits(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words) {
+    return cnt_n_to_bits_ex(n, n_len, out, out_words, 0);
+}
+int cnt_bits_to_n(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
+    return host_decode(bits, words, len, out, 32, kChunkNt, decode_dev);
+}
+int cnt_n_to_bits2(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words) {
+    return host_encode(n, n_len, out, out_words, 0, 27, kChunkNt5, encode2_dev);
+}
+int cnt_bits_to_n2(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
+    return host_decode(bits, words, len, out, 27, kChunkNt5, decode2_dev);
+}
+
+// ---- sharded tier -------------------------------------------------------------------
+// GPU k of G gets nt [k*C, min(N,(k+1)*C)), C = ceil(N/G) rounded up to a whole
+// number of 16 KiB tiles, so every shard starts on a word (and tile) boundary and
+// only the last shard has a tail.  No collective: outputs are disjoint ranges.
+int cnt_n_to_bits_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev) {
+    if (out_words < cnt_words_for(n_len)) return CNT_ECAP;
+    if (n_len == 0) return CNT_OK;
+    if (!n || !out) return CNT_EINVAL;
+    CNT_TRY(resolve_ndev(ndev, &ndev));
+    const size_t gran = 16384;
+    size_t per = (n_len + ndev - 1) / ndev;
+    per = (per + gran - 1) / gran * gran;
+    std::vector<int> rcs(ndev, CNT_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < ndev; ++k) {
+        const size_t lo = std::min(n_len, per * k), hi = std::min(n_len, per * (k + 1));
+        if (lo >= hi) continue;
+        th.emplace_back([=, &rcs] {
+            int rc = hip_rc(hipSetDevice(k));
+            if (rc == CNT_OK) rc = cnt_n_to_bits(n + lo, hi - lo, out + (lo >> 5), cnt_words_for(hi - lo));
+            rcs[k] = rc;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int rc : rcs)
+        if (rc != CNT_OK) return rc;
+    return CNT_OK;
+}
+
+int cnt_bits_to_n_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
+    if (len > (words << 5)) return CNT_ELEN;
+    if (len == 0) return CNT_OK;
+    if (!bits || !out) return CNT_EINVAL;
+    CNT_TRY(resolve_ndev(ndev, &ndev));
+    const size_t gran = 16384;
+    size_t per = (len + ndev - 1) / ndev;
+    per = (per + gran - 1) / gran * gran;
+    std::vector<int> rcs(ndev, CNT_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < ndev; ++k) {
+        const size_t lo = std::min(len, per * k), hi = std::min(len, per * (k + 1));
+        if (lo >= hi) continue;
+        th.emplace_back([=, &rcs] {
+            int rc = hip_rc(hipSetDevice(k));
+            if (rc == CNT_OK) rc = cnt_bits_to_n(bits + (lo >> 5), cnt_words_for(hi - lo), hi - lo, out + lo);
+            rcs[k] = rc;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int rc : rcs)
+        if (rc != CNT_OK) return rc;
+    return CNT_OK;
+}
+
+// ---- device tier --------------------------------------------------------------------
+int cnt_n_to_bits_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, void* stream) {
+    return encode_dev(d_n, n_len, d_out, out_words, flags, static_cast<hipStream_t>(stream));
+}
+int cnt_bits_to_n_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, void* stream) {
+    return decode_dev(d_bits, words, len, d_out, flags, static_cast<hipStream_t>(stream));
+}
+int cnt_n_to_bits2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, void* stream) {
+    return encode2_dev(d_n, n_len, d_out, out_words, flags, static_cast<hipStream_t>(stream));
+}
+int cnt_bits_to_n2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, void* stream) {
+    return decode2_dev(d_bits, words, len, d_out, flags, static_cast<hipStream_t>(stream));
+}
+
+// ---- utilities ----------------------------------------------------------------------
+int cnt_fill_random_acgt_dev(void* d_out, size_t first_nt, size_t n_len, uint64_t seed, void* stream) {
+    if (first_nt & 31) return CNT_ERANGE;
+    if (n_len == 0) return CNT_OK;
+    if (!d_out) return CNT_EINVAL;
+    const uint64_t blocks = (n_len + 31) >> 5;
+    hipLaunchKernelGGL(fill_random_acgt, dim3(generic_grid(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint8_t*>(d_out), (uint64_t)(first_nt >> 5), (uint64_t)n_len, seed,
+                       aligned(d_out, 16) ? 1 : 0);
+    return hip_rc(hipGetLastError());
+}
+
+int cnt_fill_random_acgtn_dev(void* d_out, size_t first_nt, size_t n_len, uint64_t seed, void* stream) {
+    if (first_nt % 27) return CNT_ERANGE;
+    if (n_len == 0) return CNT_OK;
+    if (!d_out) return CNT_EINVAL;
+    const uint64_t blocks = (n_len + 26) / 27;
+    hipLaunchKernelGGL(fill_random_acgtn, dim3(generic_grid(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint8_t*>(d_out), (uint64_t)(first_nt / 27), (uint64_t)n_len, seed);
+    return hip_rc(hipGetLastError());
+}
+
+int cnt_checksum_words_dev(const void* d_words, size_t first_word, size_t words, void* d_sum, void* stream) {
+    if (words == 0) return CNT_OK;
+    if (!d_words || !d_sum || !aligned(d_words, 8) || !aligned(d_sum, 8)) return CNT_EINVAL;
+    hipLaunchKernelGGL(checksum_words, dim3(std::min(generic_grid(words), 4096u)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint64_t*>(d_words), (uint64_t)first_word,
+                       (uint64_t)words, static_cast<unsigned long long*>(d_sum));
+    return hip_rc(hipGetLastError());
+}
+
+int cnt_count_mismatch_dev(const void* d_a, const void* d_b, size_t nbytes, void* d_count, void* stream) {
+    if (nbytes == 0) return CNT_OK;
+    if (!d_a || !d_b || !d_count || !aligned(d_count, 8)) return CNT_EINVAL;
+    hipLaunchKernelGGL(count_mismatch, dim3(std::min(generic_grid(nbytes >> 4), 4096u)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint8_t*>(d_a), static_cast<const uint8_t*>(d_b),
+                       (uint64_t)nbytes, (aligned(d_a, 16) && aligned(d_b, 16)) ? 1 : 0,
+                       static_cast<unsigned long long*>(d_count));
+    return hip_rc(hipGetLastError());
+}
+
+// ---- tuning -------------------------------------------------------------------------
+int cnt_set_tuning(const char* key, int value) {
+    if (!key) return CNT_EINVAL;
+    auto valid_variant = [](int v, bool enc) {
+        const int kind = v / 100, u = (v % 100) / 2;
+        if (v < 0 || kind > 2) return false;
+        if (kind == 0) return u == 2 || u == 4 || u == 8;
+        if (kind == 1) return enc ? (u == 4 || u == 8) : (u == 1 || u == 2);
+        return u == 1 || u == 2;
+    };
+    if (!strcmp(key, "encode")) {
+        if (!valid_variant(value, true)) return CNT_EINVAL;
+        g_encode_variant.store(value);
+    } else if (!strcmp(key, "decode")) {
+        if (!valid_variant(value, false)) return CNT_EINVAL;
+        g_decode_variant.store(value);
+    } else if (!strcmp(key, "encode_grid")) {
+        if (value < 0) return CNT_EINVAL;
+        g_encode_grid.store(value);
+    } else if (!strcmp(key, "decode_grid")) {
+        if (value < 0) return CNT_EINVAL;
+        g_decode_grid.store(value);
+    } else {
+        return CNT_EINVAL;
+    }
+    return CNT_OK;
+}
+
+int cnt_get_tuning(const char* key, int* value) {
+    if (!key || !value) return CNT_EINVAL;
+    if (!strcmp(key, "encode")) *value = g_encode_variant.load();
+    else if (!strcmp(key, "decode")) *value = g_decode_variant.load();
+    else if (!strcmp(key, "encode_grid")) *value = g_encode_grid.load();
+    else if (!strcmp(key, "decode_grid")) *value = g_decode_grid.load();
+    else return CNT_EINVAL;
+    return CNT_OK;
+}
+
+}  // extern "C"

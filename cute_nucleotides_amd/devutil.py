@@ -1,0 +1,58 @@
+"""Device-side helpers for benches and large-size verification (generator, checksum,
+mismatch count) over the C ABI's utility entry points.  torch is only the allocator."""
+import ctypes
+
+from ._lib import check, lib
+from .n_to_bits import _dev_guard, _stream_ptr
+
+
+def fill_random_acgt(out, seed, first_nt=0):
+    """Fill a uint8 CUDA tensor with the counter-based uniform ACGT stream (same stream the
+    oracle generates on the host, so any chunk can be regenerated there)."""
+    _dev_guard(out)
+    check(lib().cnt_fill_random_acgt_dev(ctypes.c_void_p(out.data_ptr()), first_nt, out.numel(),
+                                         seed & 0xFFFFFFFFFFFFFFFF, _stream_ptr()))
+    return out
+
+
+def fill_random_acgtn(out, seed, first_nt=0):
+    _dev_guard(out)
+    check(lib().cnt_fill_random_acgtn_dev(ctypes.c_void_p(out.data_ptr()), first_nt, out.numel(),
+                                          seed & 0xFFFFFFFFFFFFFFFF, _stream_ptr()))
+    return out
+
+
+def checksum_words(words, first_word=0):
+    """Position-salted 64-bit checksum of an int64 CUDA tensor of packed words (syncs)."""
+    torch = _dev_guard(words)
+    acc = torch.zeros(1, dtype=torch.int64, device=words.device)
+    check(lib().cnt_checksum_words_dev(ctypes.c_void_p(words.data_ptr()), first_word, words.numel(),
+                                       ctypes.c_void_p(acc.data_ptr()), _stream_ptr()))
+    return int(acc.item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def count_mismatch(a, b):
+    """Number of differing bytes between two equally sized CUDA tensors (syncs)."""
+    torch = _dev_guard(a)
+    nbytes = a.numel() * a.element_size()
+    if nbytes != b.numel() * b.element_size():
+        raise ValueError("size mismatch")
+    acc = torch.zeros(1, dtype=torch.int64, device=a.device)
+    check(lib().cnt_count_mismatch_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), nbytes,
+                                       ctypes.c_void_p(acc.data_ptr()), _stream_ptr()))
+    return int(acc.item())
+
+
+def set_tuning(key, value):
+    check(lib().cnt_set_tuning(key.encode(), int(value)))
+
+
+def get_tuning(key):
+    v = ctypes.c_int(0)
+    check(lib().cnt_get_tuning(key.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def variant(kind, unroll, nt=False):
+    """Variant id for set_tuning('encode'|'decode', ...): kind 'direct'|'lds'|'lane'."""
+    return {"direct": 0, "lds": 1, "lane": 2}[kind] * 100 + unroll * 2 + (1 if nt else 0)

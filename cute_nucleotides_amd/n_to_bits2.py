@@ -1,0 +1,58 @@
+"""Host-side mirror of the reference's `cute_nucleotides::n_to_bits2` module (src/n_to_bits2.rs):
+the 5-letter {A,C,G,T/U,N} codec, 3 nt -> 7 bits, 27 nt per u64.
+
+    n_to_bits2_hip(n)          <-> n_to_bits2_{lut,pext}(n: &[u8]) -> Vec<u64>          (:37, :118)
+    bits_to_n2_hip(bits, len)  <-> bits_to_n2_{lut,pdep}(bits: &[u64], len) -> Vec<u8>  (:78, :196)
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import CNT_STRICT_LUT, check, lib
+from .n_to_bits import _dev_guard, _p, _stream_ptr, _u8, _u64
+
+
+def n_to_bits2_hip(n):
+    n = _u8(n)
+    out = np.empty(lib().cnt_words2_for(n.size), dtype=np.uint64)
+    check(lib().cnt_n_to_bits2(_p(n), n.size, _p(out), out.size))
+    return out
+
+
+def bits_to_n2_hip(bits, length):
+    bits = _u64(bits)
+    if length > bits.size * 27:
+        check(_lib.CNT_ELEN)
+    out = np.empty(length, dtype=np.uint8)
+    check(lib().cnt_bits_to_n2(_p(bits), bits.size, length, _p(out)))
+    return out
+
+
+def words2_for(n_len):
+    return lib().cnt_words2_for(n_len)
+
+
+def n_to_bits2_dev(n, out=None, strict_lut=False):
+    torch = _dev_guard(n)
+    if n.dtype != torch.uint8:
+        raise TypeError("nucleotides must be a uint8 tensor")
+    words = lib().cnt_words2_for(n.numel())
+    if out is None:
+        out = torch.empty(words, dtype=torch.int64, device=n.device)
+    check(lib().cnt_n_to_bits2_dev(ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
+                                   out.numel(), CNT_STRICT_LUT if strict_lut else 0, _stream_ptr()))
+    return out[:words]
+
+
+def bits_to_n2_dev(bits, length, out=None):
+    torch = _dev_guard(bits)
+    if bits.dtype != torch.int64:
+        raise TypeError("packed words must be an int64 tensor (u64 bit pattern)")
+    if length > bits.numel() * 27:
+        check(_lib.CNT_ELEN)
+    if out is None:
+        out = torch.empty(length, dtype=torch.uint8, device=bits.device)
+    check(lib().cnt_bits_to_n2_dev(ctypes.c_void_p(bits.data_ptr()), bits.numel(), length,
+                                   ctypes.c_void_p(out.data_ptr()), 0, _stream_ptr()))
+    return out[:length]

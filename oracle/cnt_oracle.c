@@ -16,30 +16,20 @@
 /* n_to_bits.rs:8-21 -- a,A=00  c,C=01  t,T,u,U=10  g,G=11, every other 7-bit
  * byte 0.  The reference table has 128 entries and is indexed unchecked by a
  * raw byte (:42), i.e. UB for bytes >= 0x80; here those are defined as 0. */
-static uint8_t byte_lut(uint8_t c) {
-    switch (c) {
-    case 'a': case 'A': return 0;
-    case 'c': case 'C': return 1;
-    case 't': case 'T': case 'u': case 'U': return 2;
-    case 'g': case 'G': return 3;
-    default: return 0;
-    }
-}
+static const uint8_t BYTE_LUT[256] = {
+    ['a'] = 0, ['A'] = 0, ['c'] = 1, ['C'] = 1, ['t'] = 2, ['T'] = 2, ['u'] = 2, ['U'] = 2, ['g'] = 3, ['G'] = 3,
+};
+static inline uint8_t byte_lut(uint8_t c) { return BYTE_LUT[c]; }
 
 /* n_to_bits.rs:23-30 -- 00=A 01=C 10=T 11=G. */
 static const uint8_t BITS_LUT[4] = {'A', 'C', 'T', 'G'};
 
 /* n_to_bits2.rs:8-23 -- A0 C1 T/U2 G3 N4 (note: NOT the 2-bit file's order). */
-static uint8_t byte_lut2(uint8_t c) {
-    switch (c) {
-    case 'a': case 'A': return 0;
-    case 'c': case 'C': return 1;
-    case 't': case 'T': case 'u': case 'U': return 2;
-    case 'g': case 'G': return 3;
-    case 'n': case 'N': return 4;
-    default: return 0;
-    }
-}
+static const uint8_t BYTE_LUT2[256] = {
+    ['a'] = 0, ['A'] = 0, ['c'] = 1, ['C'] = 1, ['t'] = 2, ['T'] = 2, ['u'] = 2, ['U'] = 2,
+    ['g'] = 3, ['G'] = 3, ['n'] = 4, ['N'] = 4,
+};
+static inline uint8_t byte_lut2(uint8_t c) { return BYTE_LUT2[c]; }
 
 /* n_to_bits2.rs:25-33 */
 static const uint8_t BITS_LUT2[5] = {'A', 'C', 'T', 'G', 'N'};

@@ -1,0 +1,133 @@
+"""C-ABI surface checks that need no GPU: the library loads, exports every symbol
+include/cute_nt.h declares, and its argument validation mirrors the reference's error
+behaviour.  No compute is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from cute_nucleotides_amd import build
+
+    build.build()
+    from cute_nucleotides_amd import _lib
+
+    return _lib.lib()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cute_nt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnt_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from cute_nucleotides_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(L, name), "header declares %s but the library does not export it" % name
+        assert name in _lib.SIGNATURES, "%s not bound in _lib.SIGNATURES" % name
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cute_nucleotides_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("#", "//", "*", '"""')))
+                assert not re.search(r"^\s*(from|import)\s+oracle", code, re.M), f
+                assert "cnt_oracle" not in code and "libcnt_oracle" not in code, f
+
+
+def test_words_for(L):
+    for n in (0, 1, 31, 32, 33, 64, 2**34, 2**36 + 5):
+        assert L.cnt_words_for(n) == (n + 31) // 32
+        assert L.cnt_words2_for(n) == (n + 26) // 27
+
+
+def test_strerror_carries_the_reference_panic_text(L):
+    from cute_nucleotides_amd import _lib
+
+    assert _lib.strerror(_lib.CNT_ELEN) == "The length is greater than the number of nucleotides!"
+    assert _lib.strerror(0) == "ok"
+    for s in (1, 2, 4, 5, -1, -100, 99):
+        assert isinstance(_lib.strerror(s), str) and _lib.strerror(s)
+
+
+def test_argument_errors_before_any_device_work(L):
+    from cute_nucleotides_amd import _lib
+
+    n = np.frombuffer(b"ACGT" * 16, dtype=np.uint8)
+    out = np.zeros(1, dtype=np.uint64)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    # capacity: 64 nt need 2 words
+    assert L.cnt_n_to_bits(p(n), 64, p(out), 1) == _lib.CNT_ECAP
+    assert L.cnt_n_to_bits_dev(p(n), 64, p(out), 1, 0, None) == _lib.CNT_ECAP
+    assert L.cnt_n_to_bits2(p(n), 64, p(out), 2) == _lib.CNT_ECAP
+    # len guard (reference panic): 1 word holds 32 nt / 27 nt
+    buf = np.zeros(64, dtype=np.uint8)
+    assert L.cnt_bits_to_n(p(out), 1, 33, p(buf)) == _lib.CNT_ELEN
+    assert L.cnt_bits_to_n_dev(p(out), 1, 33, p(buf), 0, None) == _lib.CNT_ELEN
+    assert L.cnt_bits_to_n2(p(out), 1, 28, p(buf)) == _lib.CNT_ELEN
+    assert L.cnt_bits_to_n_sharded(p(out), 1, 33, p(buf), 1) == _lib.CNT_ELEN
+    # empty input -> empty output, success, no device needed (SURVEY 8a iv)
+    assert L.cnt_n_to_bits(None, 0, None, 0) == _lib.CNT_OK
+    assert L.cnt_bits_to_n(None, 0, 0, None) == _lib.CNT_OK
+    assert L.cnt_n_to_bits2(None, 0, None, 0) == _lib.CNT_OK
+    assert L.cnt_n_to_bits_dev(None, 0, None, 0, 0, None) == _lib.CNT_OK
+    # null with non-zero size
+    assert L.cnt_n_to_bits(None, 64, p(out), 2) == _lib.CNT_EINVAL
+    # unknown flag
+    assert L.cnt_n_to_bits_dev(p(n), 32, p(out), 1, 0x80, None) == _lib.CNT_EINVAL
+    # generator offsets must sit on block boundaries
+    assert L.cnt_fill_random_acgt_dev(p(buf), 5, 32, 1, None) == _lib.CNT_ERANGE
+    assert L.cnt_fill_random_acgtn_dev(p(buf), 5, 27, 1, None) == _lib.CNT_ERANGE
+
+
+def test_tuning_knobs(L):
+    from cute_nucleotides_amd import devutil
+
+    old = devutil.get_tuning("encode")
+    try:
+        for kind, unrolls in (("direct", (2, 4, 8)), ("lds", (4, 8)), ("lane", (1, 2))):
+            for u in unrolls:
+                for nt in (False, True):
+                    devutil.set_tuning("encode", devutil.variant(kind, u, nt))
+                    assert devutil.get_tuning("encode") == devutil.variant(kind, u, nt)
+        assert L.cnt_set_tuning(b"encode", 999) == 1
+        assert L.cnt_set_tuning(b"nonsense", 0) == 1
+        assert L.cnt_set_tuning(b"encode_grid", -1) == 1
+    finally:
+        devutil.set_tuning("encode", old)
+
+
+def test_host_tier_fails_loudly_without_a_gpu(L):
+    """On a box with no HIP device the product path errors out; it never computes on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cute_nucleotides_amd import n_to_bits_hip
+    from cute_nucleotides_amd._lib import CuteNtError
+
+    with pytest.raises(CuteNtError):
+        n_to_bits_hip(b"ACGT")
+
+
+def test_python_mirror_len_guard_is_a_value_error():
+    from cute_nucleotides_amd import bits_to_n2_hip, bits_to_n_hip
+
+    with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
+        bits_to_n_hip(np.zeros(1, dtype=np.uint64), 33)
+    with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
+        bits_to_n2_hip(np.zeros(1, dtype=np.uint64), 28)

@@ -1,0 +1,312 @@
+"""GPU parity tests for the 2-bit codec: the HIP path (through the C ABI) against the CPU
+oracle on the same seeded inputs, the reference's known-answer vectors, every kernel variant,
+every edge case the reference tests or leaves undefined, and -- at BASELINE.json's full
+sizes -- size-independent properties (round trip, checksum of checksums).  Bit-exact: this
+is integer/byte work."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+VALID = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
+SIZES = [1, 3, 4, 31, 32, 33, 63, 64, 65, 255, 256, 4095, 4096, 4097, 16383, 16384, 16385,
+         32768 + 5, 65536, 100003, (1 << 20), (1 << 20) + 13, (1 << 22) + 16384 + 31]
+
+ENC_VARIANTS = [("direct", 2), ("direct", 4), ("direct", 8), ("lds", 4), ("lds", 8), ("lane", 1), ("lane", 2)]
+DEC_VARIANTS = [("direct", 2), ("direct", 4), ("direct", 8), ("lds", 1), ("lds", 2), ("lane", 1), ("lane", 2)]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def cn():
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import _lib
+
+    _lib.lib()  # fail loudly here if the HIP library is missing
+    return cn
+
+
+@pytest.fixture()
+def tuning():
+    from cute_nucleotides_amd import devutil
+
+    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "encode_grid", "decode_grid")}
+    yield devutil
+    for k, v in saved.items():
+        devutil.set_tuning(k, v)
+
+
+def _words(hexes):
+    return np.array([int(h, 16) for h in hexes], dtype=np.uint64)
+
+
+def _rand_valid(n_len, seed):
+    return VALID[np.random.default_rng(seed).integers(0, VALID.size, n_len)]
+
+
+# ---- the reference's own vectors -------------------------------------------------------
+def test_reference_kats_host_and_device_tier(cn, torch_cuda, kats):
+    torch = torch_cuda
+    for k in kats["kats"]:
+        five = "bits2" in k["fn"] or "_n2_" in k["fn"]
+        if k["kind"] == "encode":
+            n = k["input_ascii"].encode()
+            want = _words(k["expected_words_hex"])
+            host = (cn.n_to_bits2_hip if five else cn.n_to_bits_hip)(n)
+            assert host.tolist() == want.tolist(), k
+            d = torch.frombuffer(bytearray(n), dtype=torch.uint8).cuda()
+            dev = (cn.n_to_bits2_dev if five else cn.n_to_bits_dev)(d).cpu().numpy().view(np.uint64)
+            assert dev.tolist() == want.tolist(), k
+        else:
+            bits = _words(k["input_words_hex"])
+            want = k["expected_ascii"].encode()
+            host = (cn.bits_to_n2_hip if five else cn.bits_to_n_hip)(bits, k["len"])
+            assert bytes(host) == want, k
+            d = torch.from_numpy(bits.view(np.int64)).cuda()
+            dev = (cn.bits_to_n2_dev if five else cn.bits_to_n_dev)(d, k["len"]).cpu().numpy()
+            assert bytes(dev) == want, k
+
+
+def test_bench_generator_input(cn, kats):
+    g = kats["bench_inputs"][0]
+    n = (g["unit"] * g["repeat"]).encode()
+    bits = cn.n_to_bits_hip(n)
+    assert bits.size == 1250 and (bits == np.uint64(0xD8D8D8D8D8D8D8D8)).all()
+    assert bytes(cn.bits_to_n_hip(bits, 40000)) == n
+
+
+# ---- encode vs oracle ------------------------------------------------------------------
+@pytest.mark.parametrize("n_len", SIZES)
+def test_encode_matches_lut_oracle_host_tier(cn, oracle, n_len):
+    n = _rand_valid(n_len, n_len)
+    assert np.array_equal(cn.n_to_bits_hip(n), oracle.n_to_bits_lut(n))
+    assert np.array_equal(cn.n_to_bits_hip(n, strict_lut=True), oracle.n_to_bits_lut(n))
+
+
+@pytest.mark.parametrize("kind,unroll", ENC_VARIANTS)
+@pytest.mark.parametrize("nt", [False, True])
+@pytest.mark.parametrize("grid", [0, 64])
+def test_encode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, kind, unroll, nt, grid):
+    torch = torch_cuda
+    tuning.set_tuning("encode", tuning.variant(kind, unroll, nt))
+    tuning.set_tuning("encode_grid", grid)
+    for n_len in (16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20)):
+        n = _rand_valid(n_len, 7 * n_len + unroll)
+        want = oracle.n_to_bits_lut(n)
+        d = torch.from_numpy(n).cuda()
+        for strict in (False, True):
+            got = cn.n_to_bits_dev(d, strict_lut=strict).cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want), (kind, unroll, nt, grid, n_len, strict)
+
+
+def test_encode_arbitrary_bytes_both_semantics(cn, oracle, torch_cuda):
+    """default == the reference SIMD variants' (byte>>1)&3; strict == n_to_bits_lut, on all
+    256 byte values (bytes >= 0x80 are defined as 0 where the reference is UB)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    for n_len in (256, 32 * 1000, 1 << 20):
+        n = rng.integers(0, 256, n_len, dtype=np.uint8)
+        n[:256] = np.arange(256, dtype=np.uint8)
+        d = torch.from_numpy(n).cuda()
+        fast = cn.n_to_bits_dev(d).cpu().numpy().view(np.uint64)
+        strict = cn.n_to_bits_dev(d, strict_lut=True).cpu().numpy().view(np.uint64)
+        assert np.array_equal(fast, oracle.n_to_bits_bitextract(n))  # n_len % 32 == 0: no LUT tail
+        assert np.array_equal(fast, oracle.n_to_bits_movemask(n))
+        assert np.array_equal(strict, oracle.n_to_bits_lut(n))
+    # ragged tail with arbitrary bytes: strict still equals the LUT oracle; the default applies
+    # (byte>>1)&3 to the tail too (documented; the reference's SIMD fns switch to the LUT there)
+    n = rng.integers(0, 256, 16384 + 77, dtype=np.uint8)
+    d = torch.from_numpy(n).cuda()
+    assert np.array_equal(cn.n_to_bits_dev(d, strict_lut=True).cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(n))
+    fast = cn.n_to_bits_dev(d).cpu().numpy().view(np.uint64)
+    codes = ((n >> 1) & 3).astype(np.uint64)
+    pad = np.zeros((-n.size) % 32, dtype=np.uint64)
+    want = np.bitwise_or.reduce(np.concatenate([codes, pad]).reshape(-1, 32) << (np.arange(32, dtype=np.uint64) * np.uint64(2)), axis=1)
+    assert np.array_equal(fast, want)
+
+
+def test_encode_unaligned_device_pointers(cn, oracle, torch_cuda):
+    torch = torch_cuda
+    n = _rand_valid(70001, 3)
+    buf = torch.zeros(n.size + 64, dtype=torch.uint8, device="cuda")
+    for off in (1, 3, 8, 15):
+        view = buf[off : off + n.size]
+        view.copy_(torch.from_numpy(n))
+        got = cn.n_to_bits_dev(view).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, oracle.n_to_bits_lut(n)), off
+
+
+def test_encode_last_word_zero_padded_and_no_overrun(cn, oracle, torch_cuda):
+    torch = torch_cuda
+    for n_len in (5, 16384 + 5, (1 << 20) + 1):
+        n = _rand_valid(n_len, n_len)
+        words = (n_len + 31) // 32
+        out = torch.full((words + 4,), -1, dtype=torch.int64, device="cuda")
+        cn.n_to_bits_dev(torch.from_numpy(n).cuda(), out=out)
+        got = out.cpu().numpy()
+        assert (got[words:] == -1).all(), "wrote past ceil(n/32) words"
+        assert np.array_equal(got[:words].view(np.uint64), oracle.n_to_bits_lut(n))
+        assert int(got[:words].view(np.uint64)[-1]) >> (2 * (n_len & 31)) == 0
+
+
+# ---- decode vs oracle ------------------------------------------------------------------
+@pytest.mark.parametrize("n_len", SIZES)
+def test_decode_matches_lut_oracle_host_tier(cn, oracle, n_len):
+    rng = np.random.default_rng(n_len + 11)
+    bits = rng.integers(0, 2**64, (n_len + 31) // 32, dtype=np.uint64)  # garbage beyond len is ignored
+    assert np.array_equal(cn.bits_to_n_hip(bits, n_len), oracle.bits_to_n_lut(bits, n_len))
+
+
+@pytest.mark.parametrize("kind,unroll", DEC_VARIANTS)
+@pytest.mark.parametrize("nt", [False, True])
+@pytest.mark.parametrize("grid", [0, 64])
+def test_decode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, kind, unroll, nt, grid):
+    torch = torch_cuda
+    tuning.set_tuning("decode", tuning.variant(kind, unroll, nt))
+    tuning.set_tuning("decode_grid", grid)
+    rng = np.random.default_rng(unroll)
+    for n_len in (16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20)):
+        bits = rng.integers(0, 2**64, (n_len + 31) // 32, dtype=np.uint64)
+        d = torch.from_numpy(bits.view(np.int64)).cuda()
+        got = cn.bits_to_n_dev(d, n_len).cpu().numpy()
+        assert np.array_equal(got, oracle.bits_to_n_lut(bits, n_len)), (kind, unroll, nt, grid, n_len)
+
+
+def test_decode_len_smaller_than_capacity_and_no_overrun(cn, oracle, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    bits = rng.integers(0, 2**64, 4096, dtype=np.uint64)
+    d = torch.from_numpy(bits.view(np.int64)).cuda()
+    for length in (0, 1, 31, 33, 16384, 16385, 4096 * 32 - 1, 4096 * 32):
+        out = torch.full((4096 * 32 + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        cn.bits_to_n_dev(d, length, out=out)
+        got = out.cpu().numpy()
+        assert (got[length:] == 0x5A).all(), "decode wrote past len"
+        assert np.array_equal(got[:length], oracle.bits_to_n_lut(bits, length))
+    with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
+        cn.bits_to_n_dev(d, 4096 * 32 + 1)
+
+
+def test_decode_unaligned_output(cn, oracle, torch_cuda):
+    torch = torch_cuda
+    bits = np.random.default_rng(4).integers(0, 2**64, 3000, dtype=np.uint64)
+    d = torch.from_numpy(bits.view(np.int64)).cuda()
+    buf = torch.zeros(3000 * 32 + 64, dtype=torch.uint8, device="cuda")
+    for off in (1, 7, 16):
+        cn.bits_to_n_dev(d, 3000 * 32 - 3, out=buf[off:])
+        assert np.array_equal(buf[off : off + 3000 * 32 - 3].cpu().numpy(), oracle.bits_to_n_lut(bits, 3000 * 32 - 3))
+
+
+def test_round_trip_case_and_u_fold(cn):
+    n = np.frombuffer(b"acgtuACGTU" * 1001, dtype=np.uint8)
+    back = cn.bits_to_n_hip(cn.n_to_bits_hip(n), n.size)
+    assert bytes(back) == bytes(n).upper().replace(b"U", b"T")
+
+
+def test_host_tier_multi_chunk(cn, oracle):
+    """> one 64 Mi-nt staging chunk, ragged: exercises the double-buffered H2D/kernel/D2H loop."""
+    n_len = (64 << 20) * 2 + 12345
+    n = oracle.fill_random_acgt(n_len, 42)
+    bits = cn.n_to_bits_hip(n)
+    assert np.array_equal(bits, oracle.n_to_bits_movemask(n))  # port == LUT oracle on valid input
+    assert np.array_equal(bits[: 1 << 16], oracle.n_to_bits_lut(n[: 32 << 16]))
+    back = cn.bits_to_n_hip(bits, n_len)
+    assert np.array_equal(back, n)
+
+
+def test_sharded_tier_single_device(cn, oracle):
+    n = oracle.fill_random_acgt((1 << 22) + 77, 9)
+    bits = cn.n_to_bits_hip_sharded(n, ndev=1)
+    assert np.array_equal(bits, oracle.n_to_bits_lut(n))
+    assert np.array_equal(cn.bits_to_n_hip_sharded(bits, n.size, ndev=1), n)
+    bits_all = cn.n_to_bits_hip_sharded(n, ndev=0)  # all visible devices
+    assert np.array_equal(bits_all, bits)
+    from cute_nucleotides_amd._lib import CuteNtError
+
+    import torch
+
+    with pytest.raises(CuteNtError):
+        cn.n_to_bits_hip_sharded(n, ndev=torch.cuda.device_count() + 1)
+
+
+# ---- device utilities used by the large-size checks --------------------------------------
+def test_device_generator_and_checksum_match_oracle(cn, oracle, torch_cuda):
+    from cute_nucleotides_amd import devutil
+
+    torch = torch_cuda
+    for n_len, first in ((1 << 20, 0), (100003, 32 * 12345), (31, 64)):
+        d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+        devutil.fill_random_acgt(d, 0x5EED, first_nt=first)
+        assert np.array_equal(d.cpu().numpy(), oracle.fill_random_acgt(n_len, 0x5EED, first_nt=first))
+    d5 = torch.empty(27 * 5000 + 11, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgtn(d5, 77, first_nt=27 * 3)
+    assert np.array_equal(d5.cpu().numpy(), oracle.fill_random_acgtn(d5.numel(), 77, first_nt=27 * 3))
+    w = np.random.default_rng(1).integers(0, 2**64, 100001, dtype=np.uint64)
+    dw = torch.from_numpy(w.view(np.int64)).cuda()
+    assert devutil.checksum_words(dw, first_word=17) == oracle.checksum_words(w, first_word=17)
+    a = torch.from_numpy(np.arange(100000, dtype=np.uint8)).cuda()
+    b = a.clone()
+    assert devutil.count_mismatch(a, b) == 0
+    b[5] += 1
+    b[99999] += 1
+    b[31337] ^= 0x80
+    assert devutil.count_mismatch(a, b) == 3
+    assert devutil.count_mismatch(a[1:], b[1:]) == 3  # unaligned path
+
+
+# ---- BASELINE.json configs[1], configs[2]: 1 GiB, bit-exact vs n_to_bits_lut + round trip ------
+def test_config_1gib_encode_bit_exact_and_round_trip(cn, oracle, torch_cuda):
+    from cute_nucleotides_amd import devutil
+
+    torch = torch_cuda
+    n_len = 1 << 30
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d, 0x5EED)
+    packed = cn.n_to_bits_dev(d)
+    back = cn.bits_to_n_dev(packed, n_len)
+    assert devutil.count_mismatch(d, back) == 0  # configs[2]: encode -> decode round trip
+    host_n = oracle.fill_random_acgt(n_len, 0x5EED)  # regenerate on the host: no PCIe copy of the input
+    want = oracle.n_to_bits_lut(host_n)  # the scalar parity oracle, all 2^30 nt
+    got = packed.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)  # configs[1]: bit-exact vs n_to_bits_lut
+    assert devutil.checksum_words(packed) == oracle.checksum_words(want)
+
+
+# ---- metric size: 16 GiB, verified through size-independent properties ----------------------
+def test_metric_16gib_round_trip_and_checksum_of_checksums(cn, oracle, torch_cuda):
+    from cute_nucleotides_amd import devutil
+
+    torch = torch_cuda
+    n_len = 1 << 34
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs ~36 GiB of free HBM")
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d, 0xC0FFEE)
+    packed = cn.n_to_bits_dev(d)
+    back = cn.bits_to_n_dev(packed, n_len)
+    assert devutil.count_mismatch(d, back) == 0
+    del back
+    # checksum of checksums: per-64 MiB-chunk checksums of the packed words; sampled chunks are
+    # reproduced by the CPU oracle from the seed alone, and the chunk sums add up to the whole.
+    chunk_nt = 64 << 20
+    chunk_w = chunk_nt // 32
+    n_chunks = n_len // chunk_nt
+    total = devutil.checksum_words(packed)
+    sums = [devutil.checksum_words(packed[c * chunk_w : (c + 1) * chunk_w], first_word=c * chunk_w) for c in range(n_chunks)]
+    assert sum(sums) % (1 << 64) == total
+    for c in (0, 1, n_chunks // 2 + 3, n_chunks - 1):
+        host_n = oracle.fill_random_acgt(chunk_nt, 0xC0FFEE, first_nt=c * chunk_nt)
+        want = oracle.n_to_bits_lut(host_n)
+        assert oracle.checksum_words(want, first_word=c * chunk_w) == sums[c], c
+        got = packed[c * chunk_w : (c + 1) * chunk_w].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), c

@@ -1,0 +1,99 @@
+"""GPU parity tests for the 5-letter {A,C,G,T/U,N} codec (reference src/n_to_bits2.rs) against
+the CPU oracle; bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALPHA = np.frombuffer(b"ACGTNacgtnUu", dtype=np.uint8)
+SIZES = [1, 2, 3, 4, 5, 26, 27, 28, 53, 54, 55, 80, 81, 82, 6911, 6912, 6913, 6912 * 3 + 5, 100003, 27 * 40000,
+         (1 << 22) + 11]
+
+
+@pytest.fixture(scope="module")
+def cn():
+    import torch
+
+    assert torch.cuda.is_available()
+    import cute_nucleotides_amd as cn
+
+    return cn
+
+
+@pytest.mark.parametrize("n_len", SIZES)
+def test_encode_decode_host_tier(cn, oracle, n_len):
+    n = ALPHA[np.random.default_rng(n_len).integers(0, ALPHA.size, n_len)]
+    want = oracle.n_to_bits2_lut(n)
+    got = cn.n_to_bits2_hip(n)
+    assert np.array_equal(got, want)
+    back = cn.bits_to_n2_hip(got, n_len)
+    assert np.array_equal(back, oracle.bits_to_n2_lut(want, n_len))
+    assert bytes(back) == bytes(n).upper().replace(b"U", b"T")
+
+
+def test_device_tier_aligned_unaligned_and_overrun(cn, oracle):
+    import torch
+
+    n_len = 6912 * 5 + 100
+    n = oracle.fill_random_acgtn(n_len, 5)
+    want = oracle.n_to_bits2_lut(n)
+    buf = torch.zeros(n_len + 64, dtype=torch.uint8, device="cuda")
+    for off in (0, 1, 16, 27):
+        v = buf[off : off + n_len]
+        v.copy_(torch.from_numpy(n))
+        out = torch.full((want.size + 3,), -1, dtype=torch.int64, device="cuda")
+        cn.n_to_bits2_dev(v, out=out)
+        got = out.cpu().numpy()
+        assert (got[want.size :] == -1).all()
+        assert np.array_equal(got[: want.size].view(np.uint64), want), off
+    dbits = torch.from_numpy(want.view(np.int64)).cuda()
+    for length in (0, 1, 26, 27, 28, 6912, 6913, n_len - 1, n_len):
+        for off in (0, 3):
+            out = torch.full((n_len + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+            cn.bits_to_n2_dev(dbits, length, out=out[off:])
+            got = out.cpu().numpy()
+            assert (got[off + length :] == 0x5A).all() and (got[:off] == 0x5A).all()
+            assert np.array_equal(got[off : off + length], oracle.bits_to_n2_lut(want, length)), (length, off)
+    with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
+        cn.bits_to_n2_dev(dbits, want.size * 27 + 1)
+
+
+def test_arbitrary_words_and_bytes(cn, oracle):
+    """Words no encoder produces (7-bit fields 125..127, bit 63 set) decode like the oracle
+    defines; strict mode encodes non-alphabet bytes as 0 like BYTE_LUT (n_to_bits2.rs:8-23)."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    bits = rng.integers(0, 2**64, 256 * 7 + 13, dtype=np.uint64)
+    d = torch.from_numpy(bits.view(np.int64)).cuda()
+    got = cn.bits_to_n2_dev(d, bits.size * 27).cpu().numpy()
+    assert np.array_equal(got, oracle.bits_to_n2_lut(bits, bits.size * 27))
+    n = rng.integers(0, 256, 6912 * 2 + 40, dtype=np.uint8)
+    dn = torch.from_numpy(n).cuda()
+    strict = cn.n_to_bits2_dev(dn, strict_lut=True).cpu().numpy().view(np.uint64)
+    assert np.array_equal(strict, oracle.n_to_bits2_lut(n))
+    fast = cn.n_to_bits2_dev(dn).cpu().numpy().view(np.uint64)
+    table = np.zeros(256, dtype=np.uint8)  # the reference SIMD table on the low 3 bits (n_to_bits2.rs:127-136)
+    for c in range(128):
+        table[c] = {1: 0, 3: 1, 4: 2, 5: 2, 6: 4, 7: 3}.get(c & 7, 0)
+    codes = table[n].astype(np.uint64)
+    codes = np.concatenate([codes, np.zeros((-codes.size) % 27, dtype=np.uint64)]).reshape(-1, 9, 3)
+    vals = codes[:, :, 0] + 5 * codes[:, :, 1] + 25 * codes[:, :, 2]
+    want = np.bitwise_or.reduce(vals << (np.arange(9, dtype=np.uint64) * np.uint64(7)), axis=1)
+    assert np.array_equal(fast, want)
+
+
+def test_large_round_trip(cn, oracle):
+    import torch
+
+    from cute_nucleotides_amd import devutil
+
+    n_len = 27 * (1 << 22) + 5  # ~108 Mi nt
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgtn(d, 11)
+    packed = cn.n_to_bits2_dev(d)
+    back = cn.bits_to_n2_dev(packed, n_len)
+    assert devutil.count_mismatch(d, back) == 0
+    m = 27 * 100000
+    host = oracle.fill_random_acgtn(m, 11)
+    assert np.array_equal(packed[: m // 27].cpu().numpy().view(np.uint64), oracle.n_to_bits2_lut(host))
