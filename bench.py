@@ -53,7 +53,8 @@ def parse_args():
 def cpu_baseline(seconds):
     """Time the oracle's x86 ports of the reference's best encoder/decoder on the host cores.
     The oracle is used here only as the timed CPU baseline (kind 'port': the reference is Rust and
-    cannot be built in this image)."""
+    cannot be built in this image).  Persistent threads: each owns one contiguous chunk and
+    re-runs it until a common deadline (ctypes releases the GIL during the C call)."""
     import threading
 
     import numpy as np
@@ -64,43 +65,57 @@ def cpu_baseline(seconds):
     if not orc.port_cpu_ok():
         return {"value": None, "unit": "Gnt/s", "cores": 0, "kind": "port", "sample": "host CPU lacks AVX2/BMI2"}
     L = orc.lib()
-    cores = os.cpu_count() or 1
-    n_len = 1 << 28  # 256 Mi nt sample, well past the host caches
-    n = orc.fill_random_acgt(n_len, 0x5EED)
-    words = n_len // 32
-    bits = np.empty(words, dtype=np.uint64)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per_thread = 16 << 20  # 16 Mi nt per thread: past any per-core share of L2/L3
+    n_len = max(1 << 28, cores * per_thread)
+    n = np.empty(n_len, dtype=np.uint8)
+    bits = np.empty(n_len // 32, dtype=np.uint64)
     out = orc._aligned_u8(n_len)
 
-    def run(fn_enc, fn_dec, threads, budget):
+    def spans_for(threads):
         per = (n_len // threads) // 32 * 32
-        spans = [(k * per, n_len if k == threads - 1 else (k + 1) * per) for k in range(threads)]
+        return [(k * per, n_len if k == threads - 1 else (k + 1) * per) for k in range(threads)]
 
-        def enc(lo, hi):
-            fn_enc(n.ctypes.data + lo, hi - lo, bits.ctypes.data + (lo // 32) * 8, (hi - lo + 31) // 32)
+    def parallel(fn, threads, budget):
+        """every thread repeats fn(lo, hi) on its span until `budget` s have passed; returns nt/s"""
+        spans = spans_for(threads)
+        counts = [0] * threads
+        gate = threading.Barrier(threads + 1)
+        deadline = [0.0]
 
-        def dec(lo, hi):
-            fn_dec(bits.ctypes.data + (lo // 32) * 8, (hi - lo + 31) // 32, hi - lo, out.ctypes.data + lo)
-
-        def sweep(f):
-            t0 = time.perf_counter()
-            passes = 0
+        def body(k):
+            gate.wait()
+            lo, hi = spans[k]
             while True:
-                if threads == 1:
-                    f(*spans[0])
-                else:
-                    ts = [threading.Thread(target=f, args=s) for s in spans]
-                    [t.start() for t in ts]
-                    [t.join() for t in ts]
-                passes += 1
-                dt = time.perf_counter() - t0
-                if dt >= budget:
-                    return passes * n_len / dt / 1e9
-        return sweep(enc), sweep(dec)
+                fn(lo, hi)
+                counts[k] += 1
+                if time.perf_counter() >= deadline[0]:
+                    break
 
-    q = max(seconds / 6.0, 0.5)
-    run(L.cnt_port_n_to_bits_movemask, L.cnt_port_bits_to_n_shuffle, cores, 0.0)  # untimed: first-touch the outputs
-    enc1, dec1 = run(L.cnt_port_n_to_bits_movemask, L.cnt_port_bits_to_n_shuffle, 1, q)
-    encN, decN = run(L.cnt_port_n_to_bits_movemask, L.cnt_port_bits_to_n_shuffle, cores, q)
+        ts = [threading.Thread(target=body, args=(k,)) for k in range(threads)]
+        [t.start() for t in ts]
+        t0 = time.perf_counter()
+        deadline[0] = t0 + budget
+        gate.wait()
+        [t.join() for t in ts]
+        dt = time.perf_counter() - t0
+        return sum(c * (hi - lo) for c, (lo, hi) in zip(counts, spans)) / dt / 1e9
+
+    def fill(lo, hi):
+        L.cnt_oracle_fill_random_acgt(n.ctypes.data + lo, lo, hi - lo, 0x5EED)
+
+    def enc(lo, hi):
+        L.cnt_port_n_to_bits_movemask(n.ctypes.data + lo, hi - lo, bits.ctypes.data + (lo // 32) * 8, (hi - lo + 31) // 32)
+
+    def dec(lo, hi):
+        L.cnt_port_bits_to_n_shuffle(bits.ctypes.data + (lo // 32) * 8, (hi - lo + 31) // 32, hi - lo, out.ctypes.data + lo)
+
+    parallel(fill, cores, 0.0)  # generate the sample (one pass, all cores); also first-touches n
+    parallel(enc, cores, 0.0)   # untimed: first-touch bits / out
+    parallel(dec, cores, 0.0)
+    q = max(seconds / 5.0, 0.5)
+    encN, decN = parallel(enc, cores, q), parallel(dec, cores, q)
+    enc1, dec1 = parallel(enc, 1, q), parallel(dec, 1, q)
     assert bytes(out[: 1 << 16]) == bytes(n[: 1 << 16])  # the timed decode really round-trips
     lut_nt = 1 << 24
     t0 = time.perf_counter()
@@ -113,10 +128,12 @@ def cpu_baseline(seconds):
     both = lambda e, d: 2.0 / (1.0 / e + 1.0 / d)  # nt converted per second over an encode pass + a decode pass
     return {
         "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
-        "sample": "256 Mi random ACGT nt; n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), "
-                  "%d threads over contiguous chunks, repeated for ~%.0f s; output preallocated" % (cores, seconds),
+        "sample": "%d Mi random ACGT nt (%d threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
+                  "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"
+                  % (n_len >> 20, cores, seconds),
         "encode_gnts": round(encN, 3), "decode_gnts": round(decN, 3),
-        "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3)},
+        "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3),
+                       "note": "one thread over the whole sample"},
         "scalar_lut_encode_gnts_1thread": round(lut_enc, 3), "cpu_model": model,
     }
 

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_TAG/ (raw rocprofv3 output of bench/profile.sh) into profiles/:
+
+  profiles/TAG_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary of `python bench.py`
+  profiles/TAG_bench_under_rocprof.json   the JSON line that same run printed
+  profiles/TAG_pmc_summary.json     per-kernel FETCH_SIZE / WRITE_SIZE means, calibration, HBM bytes
+  profiles/hbm_traffic.json         what bench.py reports as roofline.traffic (bytes per launch)
+
+Calibration (MI355X_MICROARCH.md section HBM): on gfx950 FETCH_SIZE under-reports wide coalesced
+reads, WRITE_SIZE is uncalibrated -- so both are scaled by factors measured in the same pass on
+probes with a known byte count (k_read reads exactly N bytes, k_write writes exactly N bytes).
+Counters are in KiB.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def means(path):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def pick(d, needle):
+    hits = [k for k in d if needle in k]
+    if len(hits) != 1:
+        raise SystemExit("expected exactly one kernel matching %r, got %r" % (needle, hits))
+    return hits[0]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    log2_nt = int(sys.argv[2]) if len(sys.argv) > 2 else 34
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
+    fetch = means(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"))
+    write = means(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"))
+    n = 1 << log2_nt
+    k_read, k_write = pick(fetch, "k_read<"), pick(write, "k_write<")
+    f_cal = n / (fetch[k_read][0] * 1024.0)   # true bytes per reported FETCH_SIZE byte
+    w_cal = n / (write[k_write][0] * 1024.0)
+    enc, dec = pick(fetch, "n_to_bits_"), pick(fetch, "bits_to_n_")
+
+    def traffic(name):
+        rd = fetch[name][0] * 1024.0 * f_cal
+        wr = write[name][0] * 1024.0 * w_cal
+        return {"kernel": name, "launches": fetch[name][1], "FETCH_SIZE_KiB_mean": fetch[name][0],
+                "WRITE_SIZE_KiB_mean": write[name][0], "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
+                "hbm_bytes": int(rd + wr), "algorithmic_bytes": int(1.25 * n), "ratio_to_algorithmic": round((rd + wr) / (1.25 * n), 4)}
+
+    summary = {
+        "tag": tag, "nt": n,
+        "calibration": {"fetch_scale": round(f_cal, 4), "write_scale": round(w_cal, 4),
+                        "probe_read": {"kernel": k_read, "true_bytes": n, "FETCH_SIZE_KiB_mean": fetch[k_read][0]},
+                        "probe_write": {"kernel": k_write, "true_bytes": n, "WRITE_SIZE_KiB_mean": write[k_write][0]},
+                        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); KiB units; gfx950 FETCH_SIZE reports 1/2 of wide reads"},
+        "encode": traffic(enc), "decode": traffic(dec),
+        "copy_probe": traffic(pick(fetch, "k_copy<")),
+    }
+    json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
+    json.dump({"source": "profiles/%s_pmc_summary.json" % tag, "nt": n,
+               "encode_bytes_per_launch": summary["encode"]["hbm_bytes"],
+               "decode_bytes_per_launch": summary["decode"]["hbm_bytes"]},
+              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,25 @@
+#!/bin/bash
+# bench/profile.sh TAG -- rocprofv3 evidence for one round, run on the GPU box via gpurun:
+#   1. --kernel-trace --stats over the default `python bench.py` command (per-kernel durations)
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC has 4 slots: 3 + 2 do not
+#      fit) over bench/pmc_workload.py (calibration probes + codec kernels)
+# Raw output lands under gpurun_out/prof_TAG/ (scratch); bench/parse_profiles.py condenses it
+# into profiles/ (committed).  Counters are never combined with tracing domains other than
+# kernel-trace.
+set -u
+TAG=${1:-r01}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
+    python "$REPO/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+echo "stats rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- \
+    python "$REPO/bench/pmc_workload.py" > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- \
+    python "$REPO/bench/pmc_workload.py" > "$OUT/pmc_write.log" 2>&1
+echo "pmc write rc=$?"
+find "$OUT" -type f | head -50

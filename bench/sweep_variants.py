@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.json"))
     ap.add_argument("--skip-probes", action="store_true")
     ap.add_argument("--grids", default="0,2048,4096,8192")
+    ap.add_argument("--nts", default="0,1,2,3")
     args = ap.parse_args()
 
     n = 1 << args.log2_nt
@@ -54,12 +55,13 @@ def main():
     enc = [("direct", u) for u in (2, 4, 8)] + [("lds", u) for u in (4, 8)] + [("lane", u) for u in (1, 2)]
     dec = [("direct", u) for u in (2, 4, 8)] + [("lds", u) for u in (1, 2)] + [("lane", u) for u in (1, 2)]
     cases = []
+    nts = [int(x) for x in args.nts.split(",")]  # 2*(nt loads) + (nt stores)
     for kind, u in enc:
-        for nt in (0, 1):
+        for nt in nts:
             for g in grids:
                 cases.append(("encode", kind, u, nt, g))
     for kind, u in dec:
-        for nt in (0, 1):
+        for nt in nts:
             for g in grids:
                 cases.append(("decode", kind, u, nt, g))
 
@@ -80,11 +82,11 @@ def main():
     def run(c):
         what, kind, u, nt, g = c
         if what == "encode":
-            devutil.set_tuning("encode", devutil.variant(kind, u, bool(nt)))
+            devutil.set_tuning("encode", devutil.variant(kind, u, nt_loads=nt >> 1, nt_stores=nt & 1))
             devutil.set_tuning("encode_grid", g)
             return timed(lambda: cn.n_to_bits_dev(d_in, out=d_packed), args.iters)
         if what == "decode":
-            devutil.set_tuning("decode", devutil.variant(kind, u, bool(nt)))
+            devutil.set_tuning("decode", devutil.variant(kind, u, nt_loads=nt >> 1, nt_stores=nt & 1))
             devutil.set_tuning("decode_grid", g)
             return timed(lambda: cn.bits_to_n_dev(d_packed, n, out=d_out), args.iters)
         a, b = ctypes.c_void_p(d_in.data_ptr()), ctypes.c_void_p(d_out.data_ptr())

@@ -61,7 +61,14 @@ def lib():
                 "%s is missing: build it with `python -m cute_nucleotides_amd.build` "
                 "(or __graft_entry__.build()); this package has no CPU fallback" % LIB_PATH
             )
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname
+        # libamdhip64.so.7) and loads it by file name, so it must be in the process BEFORE this
+        # library's NEEDED libamdhip64.so.7 is resolved -- then both share that one runtime.
+        # Loading in the other order maps two runtimes and the second one sees no device.
+        import torch  # noqa: F401  (device memory + streams plumbing; must precede the CDLL)
+
         L = ctypes.CDLL(LIB_PATH)
+        _assert_single_hip_runtime()
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here = ABI mismatch, fail loudly
             f.restype = res
@@ -70,6 +77,18 @@ def lib():
             raise ImportError("libcute_nt_hip ABI version mismatch")
         _lib = L
     return _lib
+
+
+def _assert_single_hip_runtime():
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    real = {os.path.realpath(p) for p in paths}
+    if len(real) > 1:
+        raise ImportError("two HIP runtimes are mapped in this process (%s): import torch before "
+                          "cute_nucleotides_amd" % ", ".join(sorted(real)))
 
 
 def strerror(status):

@@ -126,23 +126,23 @@ __device__ __forceinline__ u32x4 dec4(uint32_t x) {  // 4 packed bytes -> 16 ASC
 // ===========================================================================
 
 // DIRECT: dwordx4 load -> dword store, both coalesced.
-template <int U, bool NT, bool STRICT>
+template <int U, bool LNT, bool SNT, bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits_direct(const u32x4* __restrict__ in, uint32_t* __restrict__ out,
                                                            uint64_t n_tiles) {
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t base = t * (uint64_t)(kBlock * U) + threadIdx.x;
         u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = ld<NT>(in + base + u * kBlock);
+        for (int u = 0; u < U; ++u) v[u] = ld<LNT>(in + base + u * kBlock);
 #pragma unroll
-        for (int u = 0; u < U; ++u) st<NT>(out + base + u * kBlock, enc16<STRICT>(v[u]));
+        for (int u = 0; u < U; ++u) st<SNT>(out + base + u * kBlock, enc16<STRICT>(v[u]));
     }
 }
 
 // LDS: each wave loads U x 1 KiB coalesced, packs to U dwords per lane, writes
 // them to its private LDS slab in output order (ds_write_b32, conflict-free),
 // reads back 16 B per lane (ds_read_b128) and stores U/4 coalesced dwordx4.
-template <int U, bool NT, bool STRICT>
+template <int U, bool LNT, bool SNT, bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits_lds(const u32x4* __restrict__ in, u32x4* __restrict__ out,
                                                         uint64_t n_tiles) {
     static_assert(U % 4 == 0, "U must be a multiple of 4");
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_lds(const u32x4* __restrict_
         const u32x4* src = in + chunk * (uint64_t)(U * kWave) + lane;
         u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = ld<NT>(src + u * kWave);
+        for (int u = 0; u < U; ++u) v[u] = ld<LNT>(src + u * kWave);
 #pragma unroll
         for (int u = 0; u < U; ++u) my[u * kWave + lane] = enc16<STRICT>(v[u]);
         wave_lds_fence();
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_lds(const u32x4* __restrict_
 #pragma unroll
         for (int j = 0; j < U / 4; ++j) {
             u32x4 q = *reinterpret_cast<const u32x4*>(my + (j * kWave + lane) * 4);
-            st<NT>(dst + j * kWave, q);
+            st<SNT>(dst + j * kWave, q);
         }
         wave_lds_fence();  // WAR: next tile's writes vs this tile's reads
     }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_lds(const u32x4* __restrict_
 
 // LANE: each lane owns 64 consecutive nt (4 x 16 B loads at a 64-B lane
 // stride) and stores one 16-B vector; no LDS.  R = such groups per lane.
-template <int R, bool NT, bool STRICT>
+template <int R, bool LNT, bool SNT, bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits_lane(const u32x4* __restrict__ in, u32x4* __restrict__ out,
                                                          uint64_t n_tiles) {
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_lane(const u32x4* __restrict
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[r][k] = ld<NT>(in + (base + r * kBlock) * 4 + k);
+            for (int k = 0; k < 4; ++k) v[r][k] = ld<LNT>(in + (base + r * kBlock) * 4 + k);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             u32x4 q;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_lane(const u32x4* __restrict
             q.y = enc16<STRICT>(v[r][1]);
             q.z = enc16<STRICT>(v[r][2]);
             q.w = enc16<STRICT>(v[r][3]);
-            st<NT>(out + base + r * kBlock, q);
+            st<SNT>(out + base + r * kBlock, q);
         }
     }
 }
@@ -221,23 +221,23 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
 // ===========================================================================
 
 // DIRECT: dword load -> dwordx4 store, both coalesced.
-template <int U, bool NT>
+template <int U, bool LNT, bool SNT>
 __global__ __launch_bounds__(kBlock) void bits_to_n_direct(const uint32_t* __restrict__ in, u32x4* __restrict__ out,
                                                            uint64_t n_tiles) {
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t base = t * (uint64_t)(kBlock * U) + threadIdx.x;
         uint32_t x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = ld<NT>(in + base + u * kBlock);
+        for (int u = 0; u < U; ++u) x[u] = ld<LNT>(in + base + u * kBlock);
 #pragma unroll
-        for (int u = 0; u < U; ++u) st<NT>(out + base + u * kBlock, dec4(x[u]));
+        for (int u = 0; u < U; ++u) st<SNT>(out + base + u * kBlock, dec4(x[u]));
     }
 }
 
 // LDS: each wave loads V x 1 KiB of packed words as dwordx4 (coalesced),
 // parks them in its LDS slab (ds_write_b128), re-reads dword (j*64+lane)
 // (ds_read_b32, conflict-free) and stores 4V coalesced dwordx4 of ASCII.
-template <int V, bool NT>
+template <int V, bool LNT, bool SNT>
 __global__ __launch_bounds__(kBlock) void bits_to_n_lds(const u32x4* __restrict__ in, u32x4* __restrict__ out,
                                                         uint64_t n_tiles) {
     __shared__ __attribute__((aligned(16))) uint32_t slab[kBlock / kWave][V * kWave * 4];
@@ -248,34 +248,34 @@ __global__ __launch_bounds__(kBlock) void bits_to_n_lds(const u32x4* __restrict_
         const u32x4* src = in + chunk * (uint64_t)(V * kWave) + lane;
         u32x4 q[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) q[v] = ld<NT>(src + v * kWave);
+        for (int v = 0; v < V; ++v) q[v] = ld<LNT>(src + v * kWave);
 #pragma unroll
         for (int v = 0; v < V; ++v) *reinterpret_cast<u32x4*>(my + (v * kWave + lane) * 4) = q[v];
         wave_lds_fence();
         u32x4* dst = out + chunk * (uint64_t)(V * kWave * 4) + lane;
 #pragma unroll
-        for (int j = 0; j < 4 * V; ++j) st<NT>(dst + j * kWave, dec4(my[j * kWave + lane]));
+        for (int j = 0; j < 4 * V; ++j) st<SNT>(dst + j * kWave, dec4(my[j * kWave + lane]));
         wave_lds_fence();
     }
 }
 
 // LANE: each lane loads one 16-B vector of packed words and stores the 64 nt
 // it expands to as 4 x 16 B at a 64-B lane stride; no LDS.
-template <int R, bool NT>
+template <int R, bool LNT, bool SNT>
 __global__ __launch_bounds__(kBlock) void bits_to_n_lane(const u32x4* __restrict__ in, u32x4* __restrict__ out,
                                                          uint64_t n_tiles) {
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t base = t * (uint64_t)(kBlock * R) + threadIdx.x;  // in input-vector units
         u32x4 q[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) q[r] = ld<NT>(in + base + r * kBlock);
+        for (int r = 0; r < R; ++r) q[r] = ld<LNT>(in + base + r * kBlock);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             u32x4* dst = out + (base + r * kBlock) * 4;
-            st<NT>(dst + 0, dec4(q[r].x));
-            st<NT>(dst + 1, dec4(q[r].y));
-            st<NT>(dst + 2, dec4(q[r].z));
-            st<NT>(dst + 3, dec4(q[r].w));
+            st<SNT>(dst + 0, dec4(q[r].x));
+            st<SNT>(dst + 1, dec4(q[r].y));
+            st<SNT>(dst + 2, dec4(q[r].z));
+            st<SNT>(dst + 3, dec4(q[r].w));
         }
     }
 }

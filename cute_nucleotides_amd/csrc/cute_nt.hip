@@ -42,11 +42,11 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 
 // ---- tuning knobs -------------------------------------------------------------
 // Variant ids (see DESIGN.md "kernel variants" for the measurements behind the
-// defaults).  value = kind*100 + unroll*2 + nt:
-//   kind 0 DIRECT (unroll 2,4,8)   kind 1 LDS (unroll 4,8)   kind 2 LANE (unroll 1,2)
-constexpr int V(int kind, int unroll, int nt) { return kind * 100 + unroll * 2 + nt; }
-std::atomic<int> g_encode_variant{V(0, 4, 0)};
-std::atomic<int> g_decode_variant{V(0, 4, 0)};
+// defaults).  value = kind*100 + unroll*4 + nt, nt = 2*(non-temporal loads) + (non-temporal stores):
+//   kind 0 DIRECT (unroll 2,4,8)   kind 1 LDS (unroll 4,8 enc; 1,2 dec)   kind 2 LANE (unroll 1,2)
+constexpr int V(int kind, int unroll, int nt) { return kind * 100 + unroll * 4 + nt; }
+std::atomic<int> g_encode_variant{V(1, 4, 3)};
+std::atomic<int> g_decode_variant{V(0, 2, 3)};
 std::atomic<int> g_encode_grid{0};  // 0 = one workgroup per tile; >0 = cap, grid-stride over tiles
 std::atomic<int> g_decode_grid{0};
 
@@ -74,7 +74,7 @@ int launch_encode_main(int variant, const void* d_n, void* d_out, uint64_t n_len
 #define ENC_DIRECT(U, NT)                                                                              \
     case V(0, U, NT): {                                                                                \
         const uint64_t tile = (uint64_t)kBlock * U * 16, nt = n_len / tile;                            \
-        if (nt) hipLaunchKernelGGL((n_to_bits_direct<U, NT, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in, \
+        if (nt) hipLaunchKernelGGL((n_to_bits_direct<U, ((NT) >> 1) != 0, ((NT) & 1) != 0, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in, \
                                    static_cast<uint32_t*>(d_out), nt);                                 \
         *done_nt = nt * tile;                                                                          \
         break;                                                                                         \
@@ -82,7 +82,7 @@ int launch_encode_main(int variant, const void* d_n, void* d_out, uint64_t n_len
 #define ENC_LDS(U, NT)                                                                                 \
     case V(1, U, NT): {                                                                                \
         const uint64_t tile = (uint64_t)kBlock * U * 16, nt = n_len / tile;                            \
-        if (nt) hipLaunchKernelGGL((n_to_bits_lds<U, NT, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,    \
+        if (nt) hipLaunchKernelGGL((n_to_bits_lds<U, ((NT) >> 1) != 0, ((NT) & 1) != 0, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,    \
                                    static_cast<u32x4*>(d_out), nt);                                    \
         *done_nt = nt * tile;                                                                          \
         break;                                                                                         \
@@ -90,15 +90,15 @@ int launch_encode_main(int variant, const void* d_n, void* d_out, uint64_t n_len
 #define ENC_LANE(R, NT)                                                                                \
     case V(2, R, NT): {                                                                                \
         const uint64_t tile = (uint64_t)kBlock * R * 64, nt = n_len / tile;                            \
-        if (nt) hipLaunchKernelGGL((n_to_bits_lane<R, NT, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,   \
+        if (nt) hipLaunchKernelGGL((n_to_bits_lane<R, ((NT) >> 1) != 0, ((NT) & 1) != 0, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,   \
                                    static_cast<u32x4*>(d_out), nt);                                    \
         *done_nt = nt * tile;                                                                          \
         break;                                                                                         \
     }
     switch (variant) {
-        ENC_DIRECT(2, 0) ENC_DIRECT(2, 1) ENC_DIRECT(4, 0) ENC_DIRECT(4, 1) ENC_DIRECT(8, 0) ENC_DIRECT(8, 1)
-        ENC_LDS(4, 0) ENC_LDS(4, 1) ENC_LDS(8, 0) ENC_LDS(8, 1)
-        ENC_LANE(1, 0) ENC_LANE(1, 1) ENC_LANE(2, 0) ENC_LANE(2, 1)
+        ENC_DIRECT(2, 0) ENC_DIRECT(2, 1) ENC_DIRECT(2, 2) ENC_DIRECT(2, 3) ENC_DIRECT(4, 0) ENC_DIRECT(4, 1) ENC_DIRECT(4, 2) ENC_DIRECT(4, 3) ENC_DIRECT(8, 0) ENC_DIRECT(8, 1) ENC_DIRECT(8, 2) ENC_DIRECT(8, 3)
+        ENC_LDS(4, 0) ENC_LDS(4, 1) ENC_LDS(4, 2) ENC_LDS(4, 3) ENC_LDS(8, 0) ENC_LDS(8, 1) ENC_LDS(8, 2) ENC_LDS(8, 3)
+        ENC_LANE(1, 0) ENC_LANE(1, 1) ENC_LANE(1, 2) ENC_LANE(1, 3) ENC_LANE(2, 0) ENC_LANE(2, 1) ENC_LANE(2, 2) ENC_LANE(2, 3)
         default: return CNT_EINVAL;
     }
 #undef ENC_DIRECT
@@ -113,7 +113,7 @@ int launch_decode_main(int variant, const void* d_bits, void* d_out, uint64_t le
 #define DEC_DIRECT(U, NT)                                                                              \
     case V(0, U, NT): {                                                                                \
         const uint64_t tile = (uint64_t)kBlock * U * 16, nt = len / tile;                              \
-        if (nt) hipLaunchKernelGGL((bits_to_n_direct<U, NT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,            \
+        if (nt) hipLaunchKernelGGL((bits_to_n_direct<U, ((NT) >> 1) != 0, ((NT) & 1) != 0>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,            \
                                    static_cast<const uint32_t*>(d_bits), out, nt);                     \
         *done_nt = nt * tile;                                                                          \
         break;                                                                                         \
@@ -121,7 +121,7 @@ int launch_decode_main(int variant, const void* d_bits, void* d_out, uint64_t le
 #define DEC_LDS(Vv, NT)                                                                                \
     case V(1, Vv, NT): {                                                                               \
         const uint64_t tile = (uint64_t)kBlock * Vv * 64, nt = len / tile;                             \
-        if (nt) hipLaunchKernelGGL((bits_to_n_lds<Vv, NT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
+        if (nt) hipLaunchKernelGGL((bits_to_n_lds<Vv, ((NT) >> 1) != 0, ((NT) & 1) != 0>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
                                    static_cast<const u32x4*>(d_bits), out, nt);                        \
         *done_nt = nt * tile;                                                                          \
         break;                                                                                         \
@@ -129,15 +129,15 @@ int launch_decode_main(int variant, const void* d_bits, void* d_out, uint64_t le
 #define DEC_LANE(R, NT)                                                                                \
     case V(2, R, NT): {                                                                                \
         const uint64_t tile = (uint64_t)kBlock * R * 64, nt = len / tile;                              \
-        if (nt) hipLaunchKernelGGL((bits_to_n_lane<R, NT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
+        if (nt) hipLaunchKernelGGL((bits_to_n_lane<R, ((NT) >> 1) != 0, ((NT) & 1) != 0>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
                                    static_cast<const u32x4*>(d_bits), out, nt);                        \
         *done_nt = nt * tile;                                                                          \
         break;                                                                                         \
     }
     switch (variant) {
-        DEC_DIRECT(2, 0) DEC_DIRECT(2, 1) DEC_DIRECT(4, 0) DEC_DIRECT(4, 1) DEC_DIRECT(8, 0) DEC_DIRECT(8, 1)
-        DEC_LDS(1, 0) DEC_LDS(1, 1) DEC_LDS(2, 0) DEC_LDS(2, 1)
-        DEC_LANE(1, 0) DEC_LANE(1, 1) DEC_LANE(2, 0) DEC_LANE(2, 1)
+        DEC_DIRECT(2, 0) DEC_DIRECT(2, 1) DEC_DIRECT(2, 2) DEC_DIRECT(2, 3) DEC_DIRECT(4, 0) DEC_DIRECT(4, 1) DEC_DIRECT(4, 2) DEC_DIRECT(4, 3) DEC_DIRECT(8, 0) DEC_DIRECT(8, 1) DEC_DIRECT(8, 2) DEC_DIRECT(8, 3)
+        DEC_LDS(1, 0) DEC_LDS(1, 1) DEC_LDS(1, 2) DEC_LDS(1, 3) DEC_LDS(2, 0) DEC_LDS(2, 1) DEC_LDS(2, 2) DEC_LDS(2, 3)
+        DEC_LANE(1, 0) DEC_LANE(1, 1) DEC_LANE(1, 2) DEC_LANE(1, 3) DEC_LANE(2, 0) DEC_LANE(2, 1) DEC_LANE(2, 2) DEC_LANE(2, 3)
         default: return CNT_EINVAL;
     }
 #undef DEC_DIRECT
@@ -585,7 +585,7 @@ int cnt_count_mismatch_dev(const void* d_a, const void* d_b, size_t nbytes, void
 int cnt_set_tuning(const char* key, int value) {
     if (!key) return CNT_EINVAL;
     auto valid_variant = [](int v, bool enc) {
-        const int kind = v / 100, u = (v % 100) / 2;
+        const int kind = v / 100, u = (v % 100) / 4;
         if (v < 0 || kind > 2) return false;
         if (kind == 0) return u == 2 || u == 4 || u == 8;
         if (kind == 1) return enc ? (u == 4 || u == 8) : (u == 1 || u == 2);

@@ -53,6 +53,9 @@ def get_tuning(key):
     return v.value
 
 
-def variant(kind, unroll, nt=False):
-    """Variant id for set_tuning('encode'|'decode', ...): kind 'direct'|'lds'|'lane'."""
-    return {"direct": 0, "lds": 1, "lane": 2}[kind] * 100 + unroll * 2 + (1 if nt else 0)
+def variant(kind, unroll, nt=False, nt_loads=None, nt_stores=None):
+    """Variant id for set_tuning('encode'|'decode', ...): kind 'direct'|'lds'|'lane'; `nt` sets the
+    non-temporal hint on both loads and stores, nt_loads / nt_stores override each side."""
+    ld = bool(nt) if nt_loads is None else bool(nt_loads)
+    st = bool(nt) if nt_stores is None else bool(nt_stores)
+    return {"direct": 0, "lds": 1, "lane": 2}[kind] * 100 + unroll * 4 + 2 * int(ld) + int(st)
