@@ -249,7 +249,8 @@ def main():
                             "%.3g GiB (2^%d nt) per GPU" % (n_per / 2**30, args.log2_nt),
                 "nt_per_gpu": n_per, "nt_per_step": nt_per_step, "seed": hex(args.seed),
                 "sharding": "contiguous chunks on word boundaries, no collective" if world > 1 else "single GPU",
-                "encode_variant": devutil.get_tuning("encode"), "decode_variant": devutil.get_tuning("decode"),
+                "encode_kernel": dict(devutil.variants("encode"))[devutil.get_tuning("encode")],
+                "decode_kernel": dict(devutil.variants("decode"))[devutil.get_tuning("decode")],
             },
             "encode_gnts_per_gpu": round(n_len / (enc_ms * 1e-3) / 1e9, 3),
             "decode_gnts_per_gpu": round(n_len / (dec_ms * 1e-3) / 1e9, 3),

@@ -37,33 +37,23 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.json"))
     ap.add_argument("--skip-probes", action="store_true")
-    ap.add_argument("--grids", default="0,2048,4096,8192")
-    ap.add_argument("--nts", default="0,1,2,3")
+    ap.add_argument("--offset", type=int, default=0, help="shift every buffer by this many bytes (multiple of 16)")
     args = ap.parse_args()
 
     n = 1 << args.log2_nt
     dev = torch.device("cuda", 0)
-    d_in = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_packed = torch.empty(n // 32, dtype=torch.int64, device=dev)
-    d_out = torch.empty(n, dtype=torch.uint8, device=dev)
+    off = args.offset
+    assert off % 16 == 0
+    d_in = torch.empty(n + off, dtype=torch.uint8, device=dev)[off:]
+    d_packed = torch.empty(n // 32 + off // 8, dtype=torch.int64, device=dev)[off // 8:]
+    d_out = torch.empty(n + off, dtype=torch.uint8, device=dev)[off:]
     devutil.fill_random_acgt(d_in, 0x5EED)
     cn.n_to_bits_dev(d_in, out=d_packed)
     torch.cuda.synchronize()
     ref_sum = devutil.checksum_words(d_packed)
 
-    grids = [int(g) for g in args.grids.split(",")]
-    enc = [("direct", u) for u in (2, 4, 8)] + [("lds", u) for u in (4, 8)] + [("lane", u) for u in (1, 2)]
-    dec = [("direct", u) for u in (2, 4, 8)] + [("lds", u) for u in (1, 2)] + [("lane", u) for u in (1, 2)]
-    cases = []
-    nts = [int(x) for x in args.nts.split(",")]  # 2*(nt loads) + (nt stores)
-    for kind, u in enc:
-        for nt in nts:
-            for g in grids:
-                cases.append(("encode", kind, u, nt, g))
-    for kind, u in dec:
-        for nt in nts:
-            for g in grids:
-                cases.append(("decode", kind, u, nt, g))
+    cases = [("encode", name, i, 0, 0) for i, name in devutil.variants("encode")]
+    cases += [("decode", name, i, 0, 0) for i, name in devutil.variants("decode")]
 
     probes = None
     if not args.skip_probes:
@@ -82,12 +72,10 @@ def main():
     def run(c):
         what, kind, u, nt, g = c
         if what == "encode":
-            devutil.set_tuning("encode", devutil.variant(kind, u, nt_loads=nt >> 1, nt_stores=nt & 1))
-            devutil.set_tuning("encode_grid", g)
+            devutil.set_tuning("encode", u)
             return timed(lambda: cn.n_to_bits_dev(d_in, out=d_packed), args.iters)
         if what == "decode":
-            devutil.set_tuning("decode", devutil.variant(kind, u, nt_loads=nt >> 1, nt_stores=nt & 1))
-            devutil.set_tuning("decode_grid", g)
+            devutil.set_tuning("decode", u)
             return timed(lambda: cn.bits_to_n_dev(d_packed, n, out=d_out), args.iters)
         a, b = ctypes.c_void_p(d_in.data_ptr()), ctypes.c_void_p(d_out.data_ptr())
 
@@ -102,6 +90,8 @@ def main():
             assert devutil.checksum_words(d_packed) == ref_sum, c
         elif c[0] == "decode":
             assert devutil.count_mismatch(d_in, d_out) == 0, c
+    devutil.set_tuning("encode", 0)
+    devutil.set_tuning("decode", 0)
     devutil.fill_random_acgt(d_in, 0x5EED)  # probes scribbled on nothing we need, but be safe
     cn.n_to_bits_dev(d_in, out=d_packed)
     for _ in range(args.rounds):
@@ -125,7 +115,7 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump({"log2_nt": args.log2_nt, "rounds": args.rounds, "iters": args.iters, "rows": rows}, open(args.out, "w"), indent=1)
     for r in rows:
-        print("%-7s %-7s u=%d nt=%d grid=%-5d  %8.4f ms (min %8.4f)  %8.1f Gnt/s  %7.1f GB/s" % (
+        print("%-7s %-52s v=%d nt=%d grid=%-5d  %8.4f ms (min %8.4f)  %8.1f Gnt/s  %7.1f GB/s" % (
             r["what"], r["kind"], r["unroll"], r["nt"], r["grid"], r["ms_median"], r["ms_min"], r["gnts_median"], r["total_GBs_median"]))
 
 

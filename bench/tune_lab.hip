@@ -34,9 +34,6 @@ using namespace cnt;
 
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
 template <int AUX>
 __device__ __forceinline__ u32x4 bld128(__amdgpu_buffer_rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));

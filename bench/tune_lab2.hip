@@ -28,12 +28,8 @@ using namespace cnt;
         }                                                                                  \
     } while (0)
 
-typedef unsigned int vu4 __attribute__((__vector_size__(16)));
 typedef unsigned int vu2 __attribute__((__vector_size__(8)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
 
 // MAP 0: tile = blockIdx (dispatch order = address order; block b runs on XCD b%8)
 // MAP 1: XCD-chunked: XCD k sweeps its own contiguous 1/8 of the buffer

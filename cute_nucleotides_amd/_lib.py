@@ -41,6 +41,7 @@ SIGNATURES = {
     "cnt_count_mismatch_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "cnt_set_tuning": (_int, [ctypes.c_char_p, _int]),
     "cnt_get_tuning": (_int, [ctypes.c_char_p, ctypes.POINTER(_int)]),
+    "cnt_tuning_name": (ctypes.c_char_p, [ctypes.c_char_p, _int]),
 }
 
 _lib = None

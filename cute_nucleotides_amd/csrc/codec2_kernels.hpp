@@ -9,17 +9,21 @@
 // work on dwords: one input dword (4 nt) <-> one packed byte.
 //
 // Both directions are pure HBM streams (1.25 B/nt, zero reuse, ~5 VALU ops per
-// dword against ~60 available per dword at full bandwidth), so everything here
-// is about the memory system: 16 B per lane on the wide side, several
-// independent loads in flight per lane, 64-bit tile indexing, optional
-// non-temporal hints, and three ways of shaping the narrow side (kernel
-// variants below, selected by measurement -- see DESIGN.md):
-//
-//   DIRECT   wide side 16 B/lane coalesced, narrow side 4 B/lane coalesced.
-//   LDS      both sides 16 B/lane coalesced; a wave transposes its own
-//            1 KiB x U tile through a private LDS slab (no block barrier).
-//   LANE     each lane owns 64 consecutive nt: 4 x 16 B on the wide side
-//            (lane-strided), one 16 B access on the narrow side, no LDS.
+// dword against ~60 available per dword at full bandwidth), so the kernels are
+// shaped by the memory system alone.  What the A/B labs on MI355X found
+// (bench/tune_lab*.hip, logs under profiles/, summary in DESIGN.md):
+//   * few bytes per wave and MANY small workgroups in dispatch order beat deep
+//     unrolling or persistent grid-stride loops: the set of tiles in flight is
+//     then a compact, advancing address window;
+//   * 16 B per lane on the wide side, the narrow side simply 4 B per lane --
+//     staging the narrow side through LDS to widen it to 16 B bought nothing;
+//   * cache policy matters: streaming (nt) loads + write-through (sc1) stores for
+//     encode, plain loads + sc0|sc1|nt stores for decode;
+//   * letting each XCD (block b runs on XCD b%8) own 4 KiB-contiguous pieces of
+//     the input is worth ~1 %.
+// Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
+// per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)
+// and exposes the sc0 / nt / sc1 bits that plain C++ loads and stores cannot.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,22 +32,21 @@
 namespace cnt {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int vu4 __attribute__((__vector_size__(16)));  // the buffer builtins' 128-bit type
 
-constexpr int kBlock = 256;  // 4 waves: one per SIMD
+constexpr int kBlock = 256;  // generic / utility kernels: 4 waves, one per SIMD
 constexpr int kWave = 64;
+
+// cache-policy bits of the gfx950 buffer instructions (the builtin's `aux` operand)
+constexpr int kSC0 = 1, kNT = 2, kSC1 = 16;
 
 // ---------------------------------------------------------------------------
 // memory helpers
 // ---------------------------------------------------------------------------
-template <bool NT, typename T>
-__device__ __forceinline__ T ld(const T* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-template <bool NT, typename T>
-__device__ __forceinline__ void st(T* p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+// Wave-uniform buffer descriptor over [p, p+bytes): raw (untyped) buffer, no
+// swizzle; out-of-range lanes read 0 / drop stores (not relied upon).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
 // Order a wave's LDS writes before its own later LDS reads of other lanes'
@@ -53,6 +56,24 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Block -> tile mapping.  Dispatch is observed (never relied on for
+// correctness) to place block b on XCD b%8; with C > 1 each XCD turn covers C
+// consecutive tiles, i.e. a C-tile contiguous piece per private L2.  Bijective
+// on [0, n_tiles): whole groups of 8*C tiles are permuted, the ragged rest is
+// left in place.
+template <int C>
+__device__ __forceinline__ uint64_t tile_of_block(uint64_t b, uint64_t n_tiles) {
+    if constexpr (C == 1) {
+        return b;
+    } else {
+        constexpr uint64_t G = 8 * C;
+        const uint64_t g = b / G;
+        if ((g + 1) * G > n_tiles) return b;
+        const uint64_t r = b % G;
+        return g * G + (r % 8) * C + (r / 8);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -120,75 +141,55 @@ __device__ __forceinline__ u32x4 dec4(uint32_t x) {  // 4 packed bytes -> 16 ASC
 }
 
 // ===========================================================================
-// ENCODE kernels.  `in` = ASCII as 16-B vectors, tiles of kBlock*U vectors
-// (kBlock*U*16 nt); only whole tiles are handled here, the remainder goes to
-// n_to_bits_generic.  Tile index is 64-bit (2^36 nt = 2^32 lanes' worth).
+// ENCODE.  One workgroup = one tile of BLOCK*U*16 nt, no loop: the launch has one
+// workgroup per whole tile; the ragged remainder goes to n_to_bits_generic.
 // ===========================================================================
 
-// DIRECT: dwordx4 load -> dword store, both coalesced.
-template <int U, bool LNT, bool SNT, bool STRICT>
-__global__ __launch_bounds__(kBlock) void n_to_bits_direct(const u32x4* __restrict__ in, uint32_t* __restrict__ out,
-                                                           uint64_t n_tiles) {
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t base = t * (uint64_t)(kBlock * U) + threadIdx.x;
-        u32x4 v[U];
+// STREAM: 16-B loads (1 KiB per wave-instruction, coalesced) -> one packed dword
+// per lane per load, stored 4 B per lane (256 B per wave-instruction).
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          uint64_t n_tiles) {
+    constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t tid = threadIdx.x;
+    u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = ld<LNT>(in + base + u * kBlock);
+    for (int u = 0; u < U; ++u)
+        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + tid) * 16, 0, LAUX));
 #pragma unroll
-        for (int u = 0; u < U; ++u) st<SNT>(out + base + u * kBlock, enc16<STRICT>(v[u]));
-    }
+    for (int u = 0; u < U; ++u)
+        __builtin_amdgcn_raw_buffer_store_b32(enc16<STRICT>(v[u]), rout, (u * BLOCK + tid) * 4, 0, SAUX);
 }
 
-// LDS: each wave loads U x 1 KiB coalesced, packs to U dwords per lane, writes
-// them to its private LDS slab in output order (ds_write_b32, conflict-free),
-// reads back 16 B per lane (ds_read_b128) and stores U/4 coalesced dwordx4.
-template <int U, bool LNT, bool SNT, bool STRICT>
-__global__ __launch_bounds__(kBlock) void n_to_bits_lds(const u32x4* __restrict__ in, u32x4* __restrict__ out,
-                                                        uint64_t n_tiles) {
+// LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,
+// packs to U dwords per lane, parks them in its private LDS slab in output order
+// (ds_write_b32, conflict-free), reads back 16 B per lane (ds_read_b128) and
+// stores U/4 coalesced 16-B vectors.  No block barrier: the slab is per wave.
+template <int BLOCK, int U, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void n_to_bits_lds(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                       uint64_t n_tiles) {
     static_assert(U % 4 == 0, "U must be a multiple of 4");
-    __shared__ __attribute__((aligned(16))) uint32_t slab[kBlock / kWave][U * kWave];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* my = slab[wave];
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t chunk = t * (kBlock / kWave) + wave;  // one wave-chunk = U KiB of ASCII
-        const u32x4* src = in + chunk * (uint64_t)(U * kWave) + lane;
-        u32x4 v[U];
+    constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
+    __shared__ __attribute__((aligned(16))) uint32_t slab[BLOCK * U];
+    const uint64_t t = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* my = slab + wave * (U * kWave);
+    u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = ld<LNT>(src + u * kWave);
+    for (int u = 0; u < U; ++u)
+        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((wave * U + u) * kWave + lane) * 16, 0, LAUX));
 #pragma unroll
-        for (int u = 0; u < U; ++u) my[u * kWave + lane] = enc16<STRICT>(v[u]);
-        wave_lds_fence();
-        u32x4* dst = out + chunk * (uint64_t)(U * kWave / 4) + lane;
+    for (int u = 0; u < U; ++u) my[u * kWave + lane] = enc16<STRICT>(v[u]);
+    wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < U / 4; ++j) {
-            u32x4 q = *reinterpret_cast<const u32x4*>(my + (j * kWave + lane) * 4);
-            st<SNT>(dst + j * kWave, q);
-        }
-        wave_lds_fence();  // WAR: next tile's writes vs this tile's reads
-    }
-}
-
-// LANE: each lane owns 64 consecutive nt (4 x 16 B loads at a 64-B lane
-// stride) and stores one 16-B vector; no LDS.  R = such groups per lane.
-template <int R, bool LNT, bool SNT, bool STRICT>
-__global__ __launch_bounds__(kBlock) void n_to_bits_lane(const u32x4* __restrict__ in, u32x4* __restrict__ out,
-                                                         uint64_t n_tiles) {
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t base = t * (uint64_t)(kBlock * R) + threadIdx.x;  // in output-vector units
-        u32x4 v[R][4];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[r][k] = ld<LNT>(in + (base + r * kBlock) * 4 + k);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            u32x4 q;
-            q.x = enc16<STRICT>(v[r][0]);
-            q.y = enc16<STRICT>(v[r][1]);
-            q.z = enc16<STRICT>(v[r][2]);
-            q.w = enc16<STRICT>(v[r][3]);
-            st<SNT>(out + base + r * kBlock, q);
-        }
+    for (int j = 0; j < U / 4; ++j) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(my + (j * kWave + lane) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, q), rout, (wave * U * kWave + (j * kWave + lane) * 4) * 4, 0, SAUX);
     }
 }
 
@@ -217,67 +218,52 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
 }
 
 // ===========================================================================
-// DECODE kernels.  `out` = ASCII as 16-B vectors; whole tiles only.
+// DECODE.  One workgroup = one tile of BLOCK*U*16 nt of OUTPUT.
 // ===========================================================================
 
-// DIRECT: dword load -> dwordx4 store, both coalesced.
-template <int U, bool LNT, bool SNT>
-__global__ __launch_bounds__(kBlock) void bits_to_n_direct(const uint32_t* __restrict__ in, u32x4* __restrict__ out,
-                                                           uint64_t n_tiles) {
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t base = t * (uint64_t)(kBlock * U) + threadIdx.x;
-        uint32_t x[U];
+// STREAM: 4-B loads (256 B per wave-instruction) -> 16-B stores (1 KiB per
+// wave-instruction), both coalesced.
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void bits_to_n_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          uint64_t n_tiles) {
+    constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t tid = threadIdx.x;
+    uint32_t x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = ld<LNT>(in + base + u * kBlock);
+    for (int u = 0; u < U; ++u) x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (u * BLOCK + tid) * 4, 0, LAUX);
 #pragma unroll
-        for (int u = 0; u < U; ++u) st<SNT>(out + base + u * kBlock, dec4(x[u]));
-    }
+    for (int u = 0; u < U; ++u)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
 }
 
-// LDS: each wave loads V x 1 KiB of packed words as dwordx4 (coalesced),
-// parks them in its LDS slab (ds_write_b128), re-reads dword (j*64+lane)
-// (ds_read_b32, conflict-free) and stores 4V coalesced dwordx4 of ASCII.
-template <int V, bool LNT, bool SNT>
-__global__ __launch_bounds__(kBlock) void bits_to_n_lds(const u32x4* __restrict__ in, u32x4* __restrict__ out,
-                                                        uint64_t n_tiles) {
-    __shared__ __attribute__((aligned(16))) uint32_t slab[kBlock / kWave][V * kWave * 4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* my = slab[wave];
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t chunk = t * (kBlock / kWave) + wave;  // V KiB packed -> 4V KiB ASCII
-        const u32x4* src = in + chunk * (uint64_t)(V * kWave) + lane;
-        u32x4 q[V];
+// LDS (measured alternative): each wave loads U/4 x 1 KiB of packed words as
+// 16-B vectors, parks them in its LDS slab (ds_write_b128), re-reads dword
+// (u*64+lane) (ds_read_b32, conflict-free) and stores U coalesced 16-B vectors.
+template <int BLOCK, int U, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void bits_to_n_lds(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                       uint64_t n_tiles) {
+    static_assert(U % 4 == 0, "U must be a multiple of 4");
+    constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
+    __shared__ __attribute__((aligned(16))) uint32_t slab[BLOCK * U];
+    const uint64_t t = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* my = slab + wave * (U * kWave);
+    u32x4 q[U / 4];
 #pragma unroll
-        for (int v = 0; v < V; ++v) q[v] = ld<LNT>(src + v * kWave);
+    for (int j = 0; j < U / 4; ++j)
+        q[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (wave * U * kWave + (j * kWave + lane) * 4) * 4, 0, LAUX));
 #pragma unroll
-        for (int v = 0; v < V; ++v) *reinterpret_cast<u32x4*>(my + (v * kWave + lane) * 4) = q[v];
-        wave_lds_fence();
-        u32x4* dst = out + chunk * (uint64_t)(V * kWave * 4) + lane;
+    for (int j = 0; j < U / 4; ++j) *reinterpret_cast<u32x4*>(my + (j * kWave + lane) * 4) = q[j];
+    wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < 4 * V; ++j) st<SNT>(dst + j * kWave, dec4(my[j * kWave + lane]));
-        wave_lds_fence();
-    }
-}
-
-// LANE: each lane loads one 16-B vector of packed words and stores the 64 nt
-// it expands to as 4 x 16 B at a 64-B lane stride; no LDS.
-template <int R, bool LNT, bool SNT>
-__global__ __launch_bounds__(kBlock) void bits_to_n_lane(const u32x4* __restrict__ in, u32x4* __restrict__ out,
-                                                         uint64_t n_tiles) {
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t base = t * (uint64_t)(kBlock * R) + threadIdx.x;  // in input-vector units
-        u32x4 q[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) q[r] = ld<LNT>(in + base + r * kBlock);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            u32x4* dst = out + (base + r * kBlock) * 4;
-            st<SNT>(dst + 0, dec4(q[r].x));
-            st<SNT>(dst + 1, dec4(q[r].y));
-            st<SNT>(dst + 2, dec4(q[r].z));
-            st<SNT>(dst + 3, dec4(q[r].w));
-        }
-    }
+    for (int u = 0; u < U; ++u)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(my[u * kWave + lane])), rout,
+                                               ((wave * U + u) * kWave + lane) * 16, 0, SAUX);
 }
 
 // Generic / tail: one thread per packed word, writes min(32, len - 32w) bytes

@@ -1,0 +1,120 @@
+// codec2_launch.hpp -- the kernel-variant tables of the 2-bit codec and their launchers.
+//
+// Variant 0 of each direction is the shipped default (the measured best on MI355X at the
+// metric size, 2^34 nt); the others are kept selectable through cnt_set_tuning() so the A/B
+// numbers in DESIGN.md can be re-measured by bench/sweep_variants.py on any box.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codec2_kernels.hpp"
+
+namespace cnt {
+
+struct VariantDesc {
+    const char* name;
+    uint32_t tile_nt;  // nucleotides per workgroup
+};
+
+// ---- encode -------------------------------------------------------------------------
+constexpr VariantDesc kEncodeVariants[] = {
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1", 64 * 2 * 16},      // 0: default
+    {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16},              // 1
+    {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16},          // 2
+    {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16},               // 3: the first shape tried
+    {"lds B=256 U=4 ld=nt st=sc1", 256 * 4 * 16},                 // 4: LDS-widened stores
+    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16},                // 5: as 0 without the XCD pairing
+    {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16},              // 6
+    {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16},      // 7
+    {"stream B=256 U=4 plain", 256 * 4 * 16},                     // 8: no cache-policy bits at all
+};
+constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
+
+inline unsigned grid_of(uint64_t n_tiles) { return (unsigned)(n_tiles > 0x7FFFFFFFull ? 0x7FFFFFFFull : n_tiles); }
+
+// HIP rejects a launch whose total thread count (grid x block) exceeds 2^31-1
+// ("invalid configuration argument"): 2^36 nt in 2 KiB tiles is 2^25 workgroups of
+// 64 = 2^31 threads.  Large buffers are therefore cut into several launches of at
+// most this many tiles (a multiple of 64, so every XCD-group permutation stays whole).
+inline uint64_t max_tiles_per_launch(int block) { return ((0x7FFFFFFFull / (uint64_t)block) / 64) * 64; }
+
+// Launches the whole-tile part of an encode; *done_nt = nucleotides covered (a multiple of
+// the variant's tile).  Pointers must be 16-B aligned.  Returns 0 / 1 (bad variant).
+template <bool STRICT>
+int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_nt) {
+    if (variant < 0 || variant >= kNumEncodeVariants) return 1;
+    const uint64_t tile = kEncodeVariants[variant].tile_nt;
+    const uint64_t total_tiles = n_len / tile;
+    *done_nt = total_tiles * tile;
+    const uint64_t per_launch = max_tiles_per_launch(512);  // 512 = the largest BLOCK below
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+    const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+    const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile;
+    uint8_t* out = static_cast<uint8_t*>(d_out) + first * (tile / 4);
+    const dim3 g(grid_of(n_tiles));
+#define CNT_ENC_STREAM(B, U, C, L, S) \
+    hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), 0, s, in, out, n_tiles)
+    switch (variant) {
+        case 0: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
+        case 1: CNT_ENC_STREAM(256, 1, 1, kNT, kSC1); break;
+        case 2: CNT_ENC_STREAM(512, 1, 1, kSC0 | kNT, kSC1); break;
+        case 3: CNT_ENC_STREAM(256, 4, 1, kNT, kNT); break;
+        case 4: hipLaunchKernelGGL((n_to_bits_lds<256, 4, kNT, kSC1, STRICT>), g, dim3(256), 0, s, in, out, n_tiles); break;
+        case 5: CNT_ENC_STREAM(64, 2, 1, kNT, kSC1); break;
+        case 6: CNT_ENC_STREAM(128, 2, 1, kNT, kSC1); break;
+        case 7: CNT_ENC_STREAM(64, 2, 4, kNT, kSC1); break;
+        case 8: CNT_ENC_STREAM(256, 4, 1, 0, 0); break;
+        default: return 1;
+    }
+    }
+#undef CNT_ENC_STREAM
+    return 0;
+}
+
+// ---- decode -------------------------------------------------------------------------
+constexpr VariantDesc kDecodeVariants[] = {
+    {"stream B=128 U=2 ld=plain st=sc0|sc1|nt", 128 * 2 * 16},        // 0: default
+    {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16},        // 1
+    {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16},  // 2
+    {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16},                   // 3: the first shape tried
+    {"lds B=256 U=4 ld=nt st=sc0|sc1|nt", 256 * 4 * 16},              // 4: LDS-widened loads
+    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 128 * 2 * 16},  // 5
+    {"stream B=128 U=2 ld=nt st=sc0|sc1|nt", 128 * 2 * 16},           // 6
+    {"stream B=128 U=2 ld=plain st=sc1|nt", 128 * 2 * 16},            // 7
+    {"stream B=256 U=4 plain", 256 * 4 * 16},                         // 8: no cache-policy bits at all
+};
+constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
+
+inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_nt) {
+    if (variant < 0 || variant >= kNumDecodeVariants) return 1;
+    const uint64_t tile = kDecodeVariants[variant].tile_nt;
+    const uint64_t total_tiles = len / tile;
+    *done_nt = total_tiles * tile;
+    const uint64_t per_launch = max_tiles_per_launch(256);  // 256 = the largest BLOCK below
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+    const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+    const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * (tile / 4);
+    uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile;
+    const dim3 g(grid_of(n_tiles));
+    constexpr int kAll = kSC0 | kSC1 | kNT;
+#define CNT_DEC_STREAM(B, U, C, L, S) \
+    hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), 0, s, in, out, n_tiles)
+    switch (variant) {
+        case 0: CNT_DEC_STREAM(128, 2, 1, 0, kAll); break;
+        case 1: CNT_DEC_STREAM(256, 2, 1, 0, kAll); break;
+        case 2: CNT_DEC_STREAM(64, 2, 2, 0, kAll); break;
+        case 3: CNT_DEC_STREAM(256, 2, 1, kNT, kNT); break;
+        case 4: hipLaunchKernelGGL((bits_to_n_lds<256, 4, kNT, kAll>), g, dim3(256), 0, s, in, out, n_tiles); break;
+        case 5: CNT_DEC_STREAM(128, 2, 2, 0, kAll); break;
+        case 6: CNT_DEC_STREAM(128, 2, 1, kNT, kAll); break;
+        case 7: CNT_DEC_STREAM(128, 2, 1, 0, kSC1 | kNT); break;
+        case 8: CNT_DEC_STREAM(256, 4, 1, 0, 0); break;
+        default: return 1;
+    }
+    }
+#undef CNT_DEC_STREAM
+    return 0;
+}
+
+}  // namespace cnt

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "codec2_kernels.hpp"
+#include "codec2_launch.hpp"
 #include "codec5_kernels.hpp"
 #include "util_kernels.hpp"
 
@@ -41,109 +42,17 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? CNT_OK : -(int)e; }
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // ---- tuning knobs -------------------------------------------------------------
-// Variant ids (see DESIGN.md "kernel variants" for the measurements behind the
-// defaults).  value = kind*100 + unroll*4 + nt, nt = 2*(non-temporal loads) + (non-temporal stores):
-//   kind 0 DIRECT (unroll 2,4,8)   kind 1 LDS (unroll 4,8 enc; 1,2 dec)   kind 2 LANE (unroll 1,2)
-constexpr int V(int kind, int unroll, int nt) { return kind * 100 + unroll * 4 + nt; }
-std::atomic<int> g_encode_variant{V(1, 4, 3)};
-std::atomic<int> g_decode_variant{V(0, 2, 3)};
-std::atomic<int> g_encode_grid{0};  // 0 = one workgroup per tile; >0 = cap, grid-stride over tiles
-std::atomic<int> g_decode_grid{0};
+// Index into kEncodeVariants / kDecodeVariants (codec2_launch.hpp); 0 = shipped default.
+std::atomic<int> g_encode_variant{0};
+std::atomic<int> g_decode_variant{0};
 
-// ---- launch helpers -------------------------------------------------------------
-inline unsigned grid_for(uint64_t n_tiles, int cap) {
-    uint64_t g = n_tiles;
-    if (cap > 0 && g > (uint64_t)cap) g = (uint64_t)cap;
-    if (g > 0x7FFFFFFFull) g = 0x7FFFFFFFull;
-    return (unsigned)g;
-}
+// grid for the grid-stride kernels (5-letter codec): capped so grid x kBlock stays below
+// HIP's 2^31-1 total-thread limit; the kernels loop over the remaining tiles.
+inline unsigned grid_for(uint64_t n_tiles) { return (unsigned)std::min<uint64_t>(n_tiles, 0x7FFFFFFFull / kBlock); }
 
 inline unsigned generic_grid(uint64_t items) {
     uint64_t b = (items + kBlock - 1) / kBlock;
     return (unsigned)std::min<uint64_t>(std::max<uint64_t>(b, 1), 1u << 16);
-}
-
-struct EncodePlan {
-    uint64_t tile_nt;  // nucleotides per workgroup tile
-};
-
-template <bool STRICT>
-int launch_encode_main(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_nt) {
-    const int cap = g_encode_grid.load(std::memory_order_relaxed);
-    const u32x4* in = static_cast<const u32x4*>(d_n);
-#define ENC_DIRECT(U, NT)                                                                              \
-    case V(0, U, NT): {                                                                                \
-        const uint64_t tile = (uint64_t)kBlock * U * 16, nt = n_len / tile;                            \
-        if (nt) hipLaunchKernelGGL((n_to_bits_direct<U, ((NT) >> 1) != 0, ((NT) & 1) != 0, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in, \
-                                   static_cast<uint32_t*>(d_out), nt);                                 \
-        *done_nt = nt * tile;                                                                          \
-        break;                                                                                         \
-    }
-#define ENC_LDS(U, NT)                                                                                 \
-    case V(1, U, NT): {                                                                                \
-        const uint64_t tile = (uint64_t)kBlock * U * 16, nt = n_len / tile;                            \
-        if (nt) hipLaunchKernelGGL((n_to_bits_lds<U, ((NT) >> 1) != 0, ((NT) & 1) != 0, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,    \
-                                   static_cast<u32x4*>(d_out), nt);                                    \
-        *done_nt = nt * tile;                                                                          \
-        break;                                                                                         \
-    }
-#define ENC_LANE(R, NT)                                                                                \
-    case V(2, R, NT): {                                                                                \
-        const uint64_t tile = (uint64_t)kBlock * R * 64, nt = n_len / tile;                            \
-        if (nt) hipLaunchKernelGGL((n_to_bits_lane<R, ((NT) >> 1) != 0, ((NT) & 1) != 0, STRICT>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s, in,   \
-                                   static_cast<u32x4*>(d_out), nt);                                    \
-        *done_nt = nt * tile;                                                                          \
-        break;                                                                                         \
-    }
-    switch (variant) {
-        ENC_DIRECT(2, 0) ENC_DIRECT(2, 1) ENC_DIRECT(2, 2) ENC_DIRECT(2, 3) ENC_DIRECT(4, 0) ENC_DIRECT(4, 1) ENC_DIRECT(4, 2) ENC_DIRECT(4, 3) ENC_DIRECT(8, 0) ENC_DIRECT(8, 1) ENC_DIRECT(8, 2) ENC_DIRECT(8, 3)
-        ENC_LDS(4, 0) ENC_LDS(4, 1) ENC_LDS(4, 2) ENC_LDS(4, 3) ENC_LDS(8, 0) ENC_LDS(8, 1) ENC_LDS(8, 2) ENC_LDS(8, 3)
-        ENC_LANE(1, 0) ENC_LANE(1, 1) ENC_LANE(1, 2) ENC_LANE(1, 3) ENC_LANE(2, 0) ENC_LANE(2, 1) ENC_LANE(2, 2) ENC_LANE(2, 3)
-        default: return CNT_EINVAL;
-    }
-#undef ENC_DIRECT
-#undef ENC_LDS
-#undef ENC_LANE
-    return hip_rc(hipGetLastError());
-}
-
-int launch_decode_main(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_nt) {
-    const int cap = g_decode_grid.load(std::memory_order_relaxed);
-    u32x4* out = static_cast<u32x4*>(d_out);
-#define DEC_DIRECT(U, NT)                                                                              \
-    case V(0, U, NT): {                                                                                \
-        const uint64_t tile = (uint64_t)kBlock * U * 16, nt = len / tile;                              \
-        if (nt) hipLaunchKernelGGL((bits_to_n_direct<U, ((NT) >> 1) != 0, ((NT) & 1) != 0>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,            \
-                                   static_cast<const uint32_t*>(d_bits), out, nt);                     \
-        *done_nt = nt * tile;                                                                          \
-        break;                                                                                         \
-    }
-#define DEC_LDS(Vv, NT)                                                                                \
-    case V(1, Vv, NT): {                                                                               \
-        const uint64_t tile = (uint64_t)kBlock * Vv * 64, nt = len / tile;                             \
-        if (nt) hipLaunchKernelGGL((bits_to_n_lds<Vv, ((NT) >> 1) != 0, ((NT) & 1) != 0>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
-                                   static_cast<const u32x4*>(d_bits), out, nt);                        \
-        *done_nt = nt * tile;                                                                          \
-        break;                                                                                         \
-    }
-#define DEC_LANE(R, NT)                                                                                \
-    case V(2, R, NT): {                                                                                \
-        const uint64_t tile = (uint64_t)kBlock * R * 64, nt = len / tile;                              \
-        if (nt) hipLaunchKernelGGL((bits_to_n_lane<R, ((NT) >> 1) != 0, ((NT) & 1) != 0>), dim3(grid_for(nt, cap)), dim3(kBlock), 0, s,              \
-                                   static_cast<const u32x4*>(d_bits), out, nt);                        \
-        *done_nt = nt * tile;                                                                          \
-        break;                                                                                         \
-    }
-    switch (variant) {
-        DEC_DIRECT(2, 0) DEC_DIRECT(2, 1) DEC_DIRECT(2, 2) DEC_DIRECT(2, 3) DEC_DIRECT(4, 0) DEC_DIRECT(4, 1) DEC_DIRECT(4, 2) DEC_DIRECT(4, 3) DEC_DIRECT(8, 0) DEC_DIRECT(8, 1) DEC_DIRECT(8, 2) DEC_DIRECT(8, 3)
-        DEC_LDS(1, 0) DEC_LDS(1, 1) DEC_LDS(1, 2) DEC_LDS(1, 3) DEC_LDS(2, 0) DEC_LDS(2, 1) DEC_LDS(2, 2) DEC_LDS(2, 3)
-        DEC_LANE(1, 0) DEC_LANE(1, 1) DEC_LANE(1, 2) DEC_LANE(1, 3) DEC_LANE(2, 0) DEC_LANE(2, 1) DEC_LANE(2, 2) DEC_LANE(2, 3)
-        default: return CNT_EINVAL;
-    }
-#undef DEC_DIRECT
-#undef DEC_LDS
-#undef DEC_LANE
-    return hip_rc(hipGetLastError());
 }
 
 // ---- per-thread device context (stream + grow-only scratch) ----------------------
@@ -226,8 +135,10 @@ int encode_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, uns
     uint64_t done_nt = 0;
     if (aligned(d_n, 16) && aligned(d_out, 16)) {
         const int v = g_encode_variant.load(std::memory_order_relaxed);
-        CNT_TRY(strict ? launch_encode_main<true>(v, d_n, d_out, n_len, s, &done_nt)
-                       : launch_encode_main<false>(v, d_n, d_out, n_len, s, &done_nt));
+        if (strict ? launch_encode<true>(v, d_n, d_out, n_len, s, &done_nt)
+                   : launch_encode<false>(v, d_n, d_out, n_len, s, &done_nt))
+            return CNT_EINVAL;
+        HIP_TRY(hipGetLastError());
     }
     if (done_nt < n_len) {
         const uint64_t first_word = done_nt >> 5;
@@ -250,8 +161,10 @@ int decode_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsign
     if (!d_bits || !d_out || !aligned(d_bits, 8)) return CNT_EINVAL;
     const size_t used_words = cnt_words_for(len);
     uint64_t done_nt = 0;
-    if (aligned(d_bits, 16) && aligned(d_out, 16))
-        CNT_TRY(launch_decode_main(g_decode_variant.load(std::memory_order_relaxed), d_bits, d_out, len, s, &done_nt));
+    if (aligned(d_bits, 16) && aligned(d_out, 16)) {
+        if (launch_decode(g_decode_variant.load(std::memory_order_relaxed), d_bits, d_out, len, s, &done_nt)) return CNT_EINVAL;
+        HIP_TRY(hipGetLastError());
+    }
     if (done_nt < len) {
         const uint64_t first_word = done_nt >> 5;
         hipLaunchKernelGGL(bits_to_n_generic, dim3(generic_grid(used_words - first_word)), dim3(kBlock), 0, s,
@@ -273,7 +186,7 @@ int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, un
     if (aligned(d_n, 16)) {
         const uint64_t n_tiles = n_len / kTileBytes5;
         if (n_tiles) {
-            const unsigned g = grid_for(n_tiles, g_encode_grid.load(std::memory_order_relaxed));
+            const unsigned g = grid_for(n_tiles);
             if (strict)
                 hipLaunchKernelGGL((n_to_bits2_tiled<true>), dim3(g), dim3(kBlock), 0, s, static_cast<const u32x4*>(d_n),
                                    static_cast<uint64_t*>(d_out), n_tiles);
@@ -307,7 +220,7 @@ int decode2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsig
     if (aligned(d_out, 16)) {
         const uint64_t n_tiles = len / kTileBytes5;
         if (n_tiles) {
-            hipLaunchKernelGGL(bits_to_n2_tiled, dim3(grid_for(n_tiles, g_decode_grid.load(std::memory_order_relaxed))),
+            hipLaunchKernelGGL(bits_to_n2_tiled, dim3(grid_for(n_tiles)),
                                dim3(kBlock), 0, s, static_cast<const uint64_t*>(d_bits), static_cast<u32x4*>(d_out),
                                n_tiles);
             HIP_TRY(hipGetLastError());
@@ -584,25 +497,12 @@ int cnt_count_mismatch_dev(const void* d_a, const void* d_b, size_t nbytes, void
 // ---- tuning -------------------------------------------------------------------------
 int cnt_set_tuning(const char* key, int value) {
     if (!key) return CNT_EINVAL;
-    auto valid_variant = [](int v, bool enc) {
-        const int kind = v / 100, u = (v % 100) / 4;
-        if (v < 0 || kind > 2) return false;
-        if (kind == 0) return u == 2 || u == 4 || u == 8;
-        if (kind == 1) return enc ? (u == 4 || u == 8) : (u == 1 || u == 2);
-        return u == 1 || u == 2;
-    };
     if (!strcmp(key, "encode")) {
-        if (!valid_variant(value, true)) return CNT_EINVAL;
+        if (value < 0 || value >= kNumEncodeVariants) return CNT_EINVAL;
         g_encode_variant.store(value);
     } else if (!strcmp(key, "decode")) {
-        if (!valid_variant(value, false)) return CNT_EINVAL;
+        if (value < 0 || value >= kNumDecodeVariants) return CNT_EINVAL;
         g_decode_variant.store(value);
-    } else if (!strcmp(key, "encode_grid")) {
-        if (value < 0) return CNT_EINVAL;
-        g_encode_grid.store(value);
-    } else if (!strcmp(key, "decode_grid")) {
-        if (value < 0) return CNT_EINVAL;
-        g_decode_grid.store(value);
     } else {
         return CNT_EINVAL;
     }
@@ -613,10 +513,17 @@ int cnt_get_tuning(const char* key, int* value) {
     if (!key || !value) return CNT_EINVAL;
     if (!strcmp(key, "encode")) *value = g_encode_variant.load();
     else if (!strcmp(key, "decode")) *value = g_decode_variant.load();
-    else if (!strcmp(key, "encode_grid")) *value = g_encode_grid.load();
-    else if (!strcmp(key, "decode_grid")) *value = g_decode_grid.load();
+    else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
+    else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else return CNT_EINVAL;
     return CNT_OK;
+}
+
+const char* cnt_tuning_name(const char* key, int value) {
+    if (!key) return nullptr;
+    if (!strcmp(key, "encode") && value >= 0 && value < kNumEncodeVariants) return kEncodeVariants[value].name;
+    if (!strcmp(key, "decode") && value >= 0 && value < kNumDecodeVariants) return kDecodeVariants[value].name;
+    return nullptr;
 }
 
 }  // extern "C"

@@ -53,9 +53,7 @@ def get_tuning(key):
     return v.value
 
 
-def variant(kind, unroll, nt=False, nt_loads=None, nt_stores=None):
-    """Variant id for set_tuning('encode'|'decode', ...): kind 'direct'|'lds'|'lane'; `nt` sets the
-    non-temporal hint on both loads and stores, nt_loads / nt_stores override each side."""
-    ld = bool(nt) if nt_loads is None else bool(nt_loads)
-    st = bool(nt) if nt_stores is None else bool(nt_stores)
-    return {"direct": 0, "lds": 1, "lane": 2}[kind] * 100 + unroll * 4 + 2 * int(ld) + int(st)
+def variants(key):
+    """[(index, description)] of the selectable kernel variants for key 'encode' | 'decode'."""
+    n = get_tuning(key + "_variants")
+    return [(i, lib().cnt_tuning_name(key.encode(), i).decode()) for i in range(n)]

@@ -121,11 +121,14 @@ int cnt_checksum_words_dev(const void *d_words, size_t first_word, size_t words,
 /* *d_count (device u64, caller zeroes it) += number of differing bytes. */
 int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void *d_count, void *stream);
 
-/* Kernel-variant override for tuning/A-B runs (bench/ only; the default is the
- * measured-best variant).  key: "encode", "decode", "encode_grid", "decode_grid".
- * Returns CNT_EINVAL for unknown keys/values. */
+/* Kernel-variant override for tuning / A-B runs (bench/ only; variant 0 is the shipped,
+ * measured-best default).  key "encode" / "decode": value = variant index;
+ * cnt_get_tuning also answers "encode_variants" / "decode_variants" (the counts).
+ * cnt_tuning_name returns the variant's description (NULL when out of range).
+ * CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);
 int cnt_get_tuning(const char *key, int *value);
+const char *cnt_tuning_name(const char *key, int value);
 
 #ifdef __cplusplus
 }

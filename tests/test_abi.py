@@ -97,18 +97,22 @@ def test_argument_errors_before_any_device_work(L):
 def test_tuning_knobs(L):
     from cute_nucleotides_amd import devutil
 
-    old = devutil.get_tuning("encode")
-    try:
-        for kind, unrolls in (("direct", (2, 4, 8)), ("lds", (4, 8)), ("lane", (1, 2))):
-            for u in unrolls:
-                for nt in (False, True):
-                    devutil.set_tuning("encode", devutil.variant(kind, u, nt))
-                    assert devutil.get_tuning("encode") == devutil.variant(kind, u, nt)
-        assert L.cnt_set_tuning(b"encode", 999) == 1
-        assert L.cnt_set_tuning(b"nonsense", 0) == 1
-        assert L.cnt_set_tuning(b"encode_grid", -1) == 1
-    finally:
-        devutil.set_tuning("encode", old)
+    for key in ("encode", "decode"):
+        old = devutil.get_tuning(key)
+        assert old == 0  # the shipped default
+        n = devutil.get_tuning(key + "_variants")
+        assert n >= 2
+        try:
+            for v in range(n):
+                devutil.set_tuning(key, v)
+                assert devutil.get_tuning(key) == v
+                assert L.cnt_tuning_name(key.encode(), v)
+            assert L.cnt_set_tuning(key.encode(), n) == 1
+            assert L.cnt_set_tuning(key.encode(), -1) == 1
+            assert L.cnt_tuning_name(key.encode(), n) is None
+        finally:
+            devutil.set_tuning(key, old)
+    assert L.cnt_set_tuning(b"nonsense", 0) == 1
 
 
 def test_host_tier_fails_loudly_without_a_gpu(L):

@@ -14,8 +14,7 @@ VALID = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
 SIZES = [1, 3, 4, 31, 32, 33, 63, 64, 65, 255, 256, 4095, 4096, 4097, 16383, 16384, 16385,
          32768 + 5, 65536, 100003, (1 << 20), (1 << 20) + 13, (1 << 22) + 16384 + 31]
 
-ENC_VARIANTS = [("direct", 2), ("direct", 4), ("direct", 8), ("lds", 4), ("lds", 8), ("lane", 1), ("lane", 2)]
-DEC_VARIANTS = [("direct", 2), ("direct", 4), ("direct", 8), ("lds", 1), ("lds", 2), ("lane", 1), ("lane", 2)]
+N_VARIANTS = 9  # kEncodeVariants / kDecodeVariants in csrc/codec2_launch.hpp (checked below)
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +38,7 @@ def cn():
 def tuning():
     from cute_nucleotides_amd import devutil
 
-    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "encode_grid", "decode_grid")}
+    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode")}
     yield devutil
     for k, v in saved.items():
         devutil.set_tuning(k, v)
@@ -92,20 +91,23 @@ def test_encode_matches_lut_oracle_host_tier(cn, oracle, n_len):
     assert np.array_equal(cn.n_to_bits_hip(n, strict_lut=True), oracle.n_to_bits_lut(n))
 
 
-@pytest.mark.parametrize("kind,unroll", ENC_VARIANTS)
-@pytest.mark.parametrize("nt", [False, True])
-@pytest.mark.parametrize("grid", [0, 64])
-def test_encode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, kind, unroll, nt, grid):
+def test_variant_tables(tuning):
+    assert tuning.get_tuning("encode_variants") == N_VARIANTS == tuning.get_tuning("decode_variants")
+    assert tuning.get_tuning("encode") == 0 and tuning.get_tuning("decode") == 0  # 0 = shipped default
+    assert len({name for _, name in tuning.variants("encode")}) == N_VARIANTS
+
+
+@pytest.mark.parametrize("variant", range(N_VARIANTS))
+def test_encode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, variant):
     torch = torch_cuda
-    tuning.set_tuning("encode", tuning.variant(kind, unroll, nt))
-    tuning.set_tuning("encode_grid", grid)
-    for n_len in (16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20)):
-        n = _rand_valid(n_len, 7 * n_len + unroll)
+    tuning.set_tuning("encode", variant)
+    for n_len in (2048, 16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20), 2048 * 16 * 5 + 2048 * 3 + 17):
+        n = _rand_valid(n_len, 7 * n_len + variant)
         want = oracle.n_to_bits_lut(n)
         d = torch.from_numpy(n).cuda()
         for strict in (False, True):
             got = cn.n_to_bits_dev(d, strict_lut=strict).cpu().numpy().view(np.uint64)
-            assert np.array_equal(got, want), (kind, unroll, nt, grid, n_len, strict)
+            assert np.array_equal(got, want), (variant, n_len, strict)
 
 
 def test_encode_arbitrary_bytes_both_semantics(cn, oracle, torch_cuda):
@@ -166,19 +168,16 @@ def test_decode_matches_lut_oracle_host_tier(cn, oracle, n_len):
     assert np.array_equal(cn.bits_to_n_hip(bits, n_len), oracle.bits_to_n_lut(bits, n_len))
 
 
-@pytest.mark.parametrize("kind,unroll", DEC_VARIANTS)
-@pytest.mark.parametrize("nt", [False, True])
-@pytest.mark.parametrize("grid", [0, 64])
-def test_decode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, kind, unroll, nt, grid):
+@pytest.mark.parametrize("variant", range(N_VARIANTS))
+def test_decode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, variant):
     torch = torch_cuda
-    tuning.set_tuning("decode", tuning.variant(kind, unroll, nt))
-    tuning.set_tuning("decode_grid", grid)
-    rng = np.random.default_rng(unroll)
-    for n_len in (16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20)):
+    tuning.set_tuning("decode", variant)
+    rng = np.random.default_rng(variant)
+    for n_len in (2048, 16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20), 2048 * 16 * 5 + 2048 * 3 + 17):
         bits = rng.integers(0, 2**64, (n_len + 31) // 32, dtype=np.uint64)
         d = torch.from_numpy(bits.view(np.int64)).cuda()
         got = cn.bits_to_n_dev(d, n_len).cpu().numpy()
-        assert np.array_equal(got, oracle.bits_to_n_lut(bits, n_len)), (kind, unroll, nt, grid, n_len)
+        assert np.array_equal(got, oracle.bits_to_n_lut(bits, n_len)), (variant, n_len)
 
 
 def test_decode_len_smaller_than_capacity_and_no_overrun(cn, oracle, torch_cuda):
@@ -308,5 +307,35 @@ def test_metric_16gib_round_trip_and_checksum_of_checksums(cn, oracle, torch_cud
         host_n = oracle.fill_random_acgt(chunk_nt, 0xC0FFEE, first_nt=c * chunk_nt)
         want = oracle.n_to_bits_lut(host_n)
         assert oracle.checksum_words(want, first_word=c * chunk_w) == sums[c], c
+        got = packed[c * chunk_w : (c + 1) * chunk_w].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), c
+
+
+# ---- BASELINE.json configs[3]: encode + decode over a 64 GiB buffer (144 GiB resident) ----------
+def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda):
+    """2^36 nt needs 2^25 workgroups x 64 threads = 2^31 threads, one more than HIP allows in a
+    launch, so this also covers the launcher's split into several launches."""
+    from cute_nucleotides_amd import devutil
+
+    torch = torch_cuda
+    n_len = 1 << 36
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs ~144 GiB of free HBM")
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d, 0xBEEF)
+    packed = cn.n_to_bits_dev(d)
+    back = cn.bits_to_n_dev(packed, n_len)
+    assert devutil.count_mismatch(d, back) == 0
+    del back
+    chunk_nt = 16 << 20
+    chunk_w = chunk_nt // 32
+    n_chunks = n_len // chunk_nt
+    # chunks around the launch split points (2^31-1 threads / 64 = 33554368 tiles of 2 KiB) and the ends
+    split_nt = ((0x7FFFFFFF // 512) // 64) * 64 * 2048
+    picks = {0, n_chunks - 1, split_nt // chunk_nt - 1, split_nt // chunk_nt, min(n_chunks - 1, 2 * split_nt // chunk_nt)}
+    for c in sorted(picks):
+        host_n = oracle.fill_random_acgt(chunk_nt, 0xBEEF, first_nt=c * chunk_nt)
+        want = oracle.n_to_bits_lut(host_n)
         got = packed[c * chunk_w : (c + 1) * chunk_w].cpu().numpy().view(np.uint64)
         assert np.array_equal(got, want), c
