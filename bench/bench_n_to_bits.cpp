@@ -1,0 +1,101 @@
+// bench_n_to_bits.cpp -- C++ twin of the reference's criterion harness
+// (benches/bench_n_to_bits.rs) for the HIP back-end: the same four groups, the same inputs
+// ("ATCG" x 10000 / "ATCGN" x 8000 = 40 000 nt), the same throughput unit (input nucleotides
+// = bytes per second, GiB/s) and the same rule that every timed call allocates its output
+// (bench_n_to_bits.rs:6-7) -- the `*_hip` functions of cute_nucleotides.hpp return fresh
+// vectors exactly like the Rust functions return fresh Vecs.  A `memcpy` row is the
+// reference's comparator (:20).  A second table repeats the host-tier calls at 1 MiB ..
+// 1 GiB, where the drop-in signature is PCIe-bound rather than latency-bound.
+//
+//   hipcc -O2 -std=c++17 -o bench/bench_n_to_bits bench/bench_n_to_bits.cpp \
+//         -Lcute_nucleotides_amd -lcute_nt_hip -Wl,-rpath,'$ORIGIN/../cute_nucleotides_amd'
+//
+// The CPU rows of the reference's table (n_to_bits_lut, _pext, ... on the host cores) are
+// produced by bench.py's cpu_baseline leg, which is the only bench allowed to call oracle/.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../cute_nucleotides_amd/cute_nucleotides.hpp"
+
+using namespace cute_nucleotides;
+using clk = std::chrono::steady_clock;
+
+static volatile uint64_t g_sink;
+
+static std::vector<uint8_t> repeat(const char* unit, size_t times) {
+    std::vector<uint8_t> v;
+    const size_t m = strlen(unit);
+    v.reserve(m * times);
+    for (size_t i = 0; i < times; ++i) v.insert(v.end(), unit, unit + m);
+    return v;
+}
+
+// criterion-like: warm up ~0.3 s, then time batches for ~1 s; mean per iteration
+static void bench_function(const char* group, const char* name, size_t throughput_bytes, const std::function<void()>& f) {
+    auto t0 = clk::now();
+    size_t warm = 0;
+    while (std::chrono::duration<double>(clk::now() - t0).count() < 0.3) { f(); ++warm; }
+    const size_t batch = warm / 10 + 1;
+    size_t iters = 0;
+    t0 = clk::now();
+    double el = 0;
+    while ((el = std::chrono::duration<double>(clk::now() - t0).count()) < 1.0) {
+        for (size_t i = 0; i < batch; ++i) f();
+        iters += batch;
+    }
+    const double per = el / iters;
+    printf("%-12s %-22s time: %10.3f us   thrpt: %9.4f GiB/s  (%.3f Gnt/s)\n", group, name, per * 1e6,
+           throughput_bytes / per / (double)(1ull << 30), throughput_bytes / per / 1e9);
+}
+
+int main() {
+    int ndev = 0;
+    if (cnt_device_count(&ndev) != CNT_OK || ndev == 0) {
+        fprintf(stderr, "no HIP device: this harness drives the GPU back-end only\n");
+        return 1;
+    }
+    // ---- the reference's groups (bench_n_to_bits.rs:9-63) -----------------------------------
+    {
+        const auto n = repeat("ATCG", 10000);  // get_nucleotides(10000), :68-70
+        bench_function("n_to_bits", "n_to_bits_hip", 40000, [&] { g_sink += n_to_bits::n_to_bits_hip(n).back(); });
+        bench_function("n_to_bits", "memcpy", 40000, [&] {
+            std::vector<uint8_t> dest(n.size());
+            memcpy(dest.data(), n.data(), n.size());
+            g_sink += dest.back();
+        });
+        const auto bits = n_to_bits::n_to_bits_hip(n);  // get_bits(10000), :76-78
+        bench_function("bits_to_n", "bits_to_n_hip", 40000, [&] { g_sink += n_to_bits::bits_to_n_hip(bits, 40000).back(); });
+    }
+    {
+        const auto n = repeat("ATCGN", 8000);  // get_nucleotides_undetermined(8000), :72-74
+        bench_function("n_to_bits2", "n_to_bits2_hip", 40000, [&] { g_sink += n_to_bits2::n_to_bits2_hip(n).back(); });
+        const auto bits = n_to_bits2::n_to_bits2_hip(n);
+        bench_function("bits_to_n2", "bits_to_n2_hip", 40000, [&] { g_sink += n_to_bits2::bits_to_n2_hip(bits, 40000).back(); });
+    }
+    // ---- the same drop-in calls at sizes where PCIe, not launch latency, is the bound ---------
+    for (size_t log2 : {20, 26, 30}) {
+        const size_t len = (size_t)1 << log2;
+        std::vector<uint8_t> n(len);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < len; ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;  // xorshift64
+            n[i] = "ACGT"[x & 3];
+        }
+        char nm[64];
+        snprintf(nm, sizeof nm, "n_to_bits_hip/2^%zu", log2);
+        bench_function("host-tier", nm, len, [&] { g_sink += n_to_bits::n_to_bits_hip(n).back(); });
+        const auto bits = n_to_bits::n_to_bits_hip(n);
+        snprintf(nm, sizeof nm, "bits_to_n_hip/2^%zu", log2);
+        bench_function("host-tier", nm, len, [&] { g_sink += n_to_bits::bits_to_n_hip(bits, len).back(); });
+        if (n_to_bits::bits_to_n_hip(bits, len) != n) {
+            fprintf(stderr, "round trip mismatch at 2^%zu\n", log2);
+            return 2;
+        }
+    }
+    cnt_shutdown();
+    return 0;
+}
