@@ -5,8 +5,12 @@
 // (7 bits), 9 triplets (27 nt) per u64, bit 63 always 0.
 //
 // 27-nt words do not line up with power-of-two vectors (64 B of ASCII = 2.37
-// words), so a workgroup stages a tile of ASCII through LDS with coalesced
-// 16-B global accesses and each lane then works on one whole word from LDS.
+// words), which is where LDS earns its keep on this path: a WAVE owns 64 words =
+// 1728 B of ASCII = 108 x 16 B, moves them between HBM and its private LDS slab
+// with coalesced 16-B accesses, and each lane works on one whole word out of LDS.
+// Slabs are per wave, so there is no workgroup barrier -- only the wave-level
+// ordering fence -- and workgroups can be a single wave (the 2-bit codec's lesson:
+// many tiny workgroups stream best).  Same cache-policy bits as the 2-bit kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -126,74 +130,129 @@ __global__ __launch_bounds__(kBlock) void bits_to_n2_generic(const uint64_t* __r
 }
 
 // ---------------------------------------------------------------------------
-// Tiled kernels: a workgroup handles kWordsPerTile words = 27*kWordsPerTile nt.
-// 27 * 256 = 6912 B = 432 x 16 B: whole 16-B vectors, so tiles start 16-B
-// aligned whenever the buffer does.
+// Wave-tiled kernels.  One wave owns WPL*64 consecutive words = WPL*1728 B of ASCII
+// (WPL words per lane).  WPL is even so that every wave tile is a whole number of
+// 128-B cache lines on BOTH sides (1728 B = 13.5 lines: with WPL = 1 neighbouring
+// waves split a line, which costs ~30 % on this chip -- same effect as a misaligned
+// buffer).  A workgroup of WAVES waves handles WAVES consecutive wave tiles; slabs are
+// per wave, so the only synchronisation is the wave-level LDS fence.
 // ---------------------------------------------------------------------------
-constexpr int kWords5 = kBlock;                 // words per tile: one per lane
-constexpr int kTileBytes5 = 27 * kWords5;       // 6912
-constexpr int kTileVecs5 = kTileBytes5 / 16;    // 432
-static_assert(kTileBytes5 % 16 == 0, "tile must be whole 16-B vectors");
+constexpr int kWaveWords5 = 64;                 // words per wave per round
+constexpr int kWaveBytes5 = 27 * kWaveWords5;   // 1728 B of ASCII per round
+constexpr int kWaveVecs5 = kWaveBytes5 / 16;    // 108
+constexpr int kWaveDwords5 = kWaveBytes5 / 4;   // 432
+static_assert(kWaveBytes5 % 16 == 0, "a round must be whole 16-B vectors");
 
-// Encode: coalesced 16-B loads of the ASCII tile into LDS, then lane l reads
-// its 27 bytes (7 unaligned-safe dword reads via byte-assembled funnel shifts),
-// packs, and stores one u64 (8 B/lane, coalesced).
-template <bool STRICT>
-__global__ __launch_bounds__(kBlock) void n_to_bits2_tiled(const u32x4* __restrict__ in, uint64_t* __restrict__ out,
-                                                           uint64_t n_tiles) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileBytes5 / 4 + 4];
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const u32x4* src = in + t * (uint64_t)kTileVecs5;
-        u32x4 a = src[threadIdx.x];
-        u32x4 b;
-        const bool second = threadIdx.x + kBlock < kTileVecs5;
-        if (second) b = src[threadIdx.x + kBlock];
-        __syncthreads();  // previous iteration's readers are done
-        *reinterpret_cast<u32x4*>(tile + threadIdx.x * 4) = a;
-        if (second) *reinterpret_cast<u32x4*>(tile + (threadIdx.x + kBlock) * 4) = b;
-        __syncthreads();
-        // lane's 27 bytes start at byte 27*l: dword index q = (27*l)>>2, byte phase s = (27*l)&3
-        const uint32_t byte0 = 27u * threadIdx.x;
-        const uint32_t q = byte0 >> 2, s8 = (byte0 & 3u) * 8u;
+// Encode: WPL*108 coalesced 16-B loads into the wave's LDS slab; then, per round j, lane l
+// reads the 8 dwords that cover the 27 bytes of word j*64+l, funnel-shifts them into place,
+// maps 4 bytes at a time to codes with v_perm_b32, and stores one u64 (8 B per lane,
+// 512 B per wave-instruction).
+template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                               uint64_t n_wave_tiles) {
+    constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
+    __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t t = blockIdx.x * (uint64_t)WAVES + wave;
+    if (t >= n_wave_tiles) return;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, TILE_BYTES);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
+    uint32_t* my = slab[wave];
+    constexpr int NLD = (TILE_VECS + 63) / 64;
+    u32x4 v[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        v[i] = u32x4{0, 0, 0, 0};
+        if ((i + 1) * 64 <= TILE_VECS || lane < TILE_VECS - i * 64)
+            v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+        if ((i + 1) * 64 <= TILE_VECS || lane < TILE_VECS - i * 64) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
+    wave_lds_fence();
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) {
+        const uint32_t byte0 = 27u * lane;  // + 1728*j, which is dword aligned: same phase every round
+        const uint32_t q = (byte0 >> 2) + kWaveDwords5 * j, s8 = (byte0 & 3u) * 8u;
         uint32_t raw[8];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) raw[d] = tile[q + d];  // q+7 <= 1727+... within the +4 pad
+        for (int d = 0; d < 8; ++d) raw[d] = my[q + d];  // q + 7 <= 432*WPL + 3: inside the padded slab
         uint32_t c[7];
 #pragma unroll
         for (int d = 0; d < 7; ++d) {
-            // funnel shift right by s8 bits across raw[d], raw[d+1]
-            uint32_t x = (uint32_t)((((uint64_t)raw[d + 1] << 32) | raw[d]) >> s8);
-            if (d == 6) x &= 0x00FFFFFFu;  // bytes 24..26 only
+            uint32_t x = (uint32_t)((((uint64_t)raw[d + 1] << 32) | raw[d]) >> s8);  // funnel shift right by the byte phase
+            if (d == 6) x &= 0x00FFFFFFu;                                             // bytes 24..26 only
             c[d] = code5<STRICT>(x);
         }
-        out[t * (uint64_t)kWords5 + threadIdx.x] = pack27(c);
+        const uint64_t word = pack27(c);
+        const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
     }
 }
 
-// Decode: lane l expands word l into 27 letters written to LDS (byte stores
-// assembled as dwords is awkward at a 27-B pitch, so write bytes via
-// 7 funnel-merged dwords is avoided: each lane writes its 27 bytes with
-// ds_write_b8), then the tile leaves with coalesced 16-B stores.
-__global__ __launch_bounds__(kBlock) void bits_to_n2_tiled(const uint64_t* __restrict__ in, u32x4* __restrict__ out,
-                                                           uint64_t n_tiles) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kTileBytes5];
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t word = in[t * (uint64_t)kWords5 + threadIdx.x];
-        __syncthreads();
-        uint8_t* dst = tile + 27u * threadIdx.x;
+// Decode: per round j, lane l loads word j*64+l (8 B, 512 B per wave-instruction), expands
+// it to 27 letters held as 7 dwords, shifts them to the byte phase of position 27*l,
+// completes the dword it shares with lane l-1 by one wave shuffle, and writes 6-7 ALIGNED
+// dwords to the wave's LDS slab (every slab dword is written by exactly one lane -- no byte
+// stores; rounds are independent because 1728 B is dword aligned).  The tile then leaves
+// with WPL*108 coalesced 16-B stores.
+template <int WAVES, int WPL, int LAUX, int SAUX>
+__global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                               uint64_t n_wave_tiles) {
+    constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
+    __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t t = blockIdx.x * (uint64_t)WAVES + wave;
+    if (t >= n_wave_tiles) return;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * (TILE_WORDS * 8), TILE_WORDS * 8);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_BYTES, TILE_BYTES);
+    uint32_t* my = slab[wave];
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    vu2 w2[WPL];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            uint32_t l = letters5(digits3((uint32_t)(word >> (7 * k)) & 0x7Fu));
-            dst[3 * k + 0] = (uint8_t)l;
-            dst[3 * k + 1] = (uint8_t)(l >> 8);
-            dst[3 * k + 2] = (uint8_t)(l >> 16);
-        }
-        __syncthreads();
-        u32x4* o = out + t * (uint64_t)kTileVecs5;
-        o[threadIdx.x] = *reinterpret_cast<const u32x4*>(tile + threadIdx.x * 16);
-        if (threadIdx.x + kBlock < kTileVecs5)
-            o[threadIdx.x + kBlock] = *reinterpret_cast<const u32x4*>(tile + (threadIdx.x + kBlock) * 16);
+    for (int j = 0; j < WPL; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) {
+        const uint64_t word = ((uint64_t)w2[j][1] << 32) | w2[j][0];
+        uint32_t L[9];  // 3 letters per triplet in the low 24 bits
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L[k] = letters5(digits3((uint32_t)(word >> (7 * k)) & 0x7Fu)) & 0x00FFFFFFu;
+        // the lane's 27 bytes as 7 dwords (b[6] holds 3 bytes), plus a zero guard
+        uint32_t b[8];
+        b[0] = L[0] | (L[1] << 24);
+        b[1] = (L[1] >> 8) | (L[2] << 16);
+        b[2] = (L[2] >> 16) | (L[3] << 8);
+        b[3] = L[4] | (L[5] << 24);
+        b[4] = (L[5] >> 8) | (L[6] << 16);
+        b[5] = (L[6] >> 16) | (L[7] << 8);
+        b[6] = L[8];
+        b[7] = 0;
+        // window of 8 aligned dwords starting at dword (27*lane)>>2, bytes shifted left by the phase
+        const uint32_t byte0 = 27u * lane, q0 = byte0 >> 2, s8 = (byte0 & 3u) * 8u;
+        uint32_t W[8];
+        W[0] = (uint32_t)(((uint64_t)b[0] << s8));
+#pragma unroll
+        for (int k = 1; k < 8; ++k) W[k] = (uint32_t)(((((uint64_t)b[k] << 32) | b[k - 1]) << s8) >> 32);
+        // complete dwords this lane owns: q0 .. ((27*(lane+1))>>2) - 1 (6 or 7 of them); the
+        // partial one after them belongs to lane+1, which receives it through the shuffle
+        const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
+        const uint32_t tail = cnt == 6 ? W[6] : W[7];
+        const uint32_t prev_tail = __shfl_up(tail, 1, 64);
+        if (s8 != 0) W[0] |= prev_tail;  // lane 0 has s8 == 0
+        uint32_t* dst = my + kWaveDwords5 * j + q0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dst[k] = W[k];
+        if (cnt == 7) dst[6] = W[6];
     }
+    wave_lds_fence();
+    constexpr int NST = (TILE_VECS + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if ((i + 1) * 64 <= TILE_VECS || lane < TILE_VECS - i * 64) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(my + (i * 64 + lane) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
+        }
 }
 
 }  // namespace cnt

@@ -1,0 +1,90 @@
+// codec5_launch.hpp -- kernel-variant tables + launchers of the 5-letter codec (see
+// codec2_launch.hpp for the conventions: variant 0 = shipped default, the rest selectable
+// through cnt_set_tuning("encode2" / "decode2", i) for A/B runs).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codec2_launch.hpp"
+#include "codec5_kernels.hpp"
+
+namespace cnt {
+
+// tile_nt = nucleotides per WAVE tile (WPL * 1728); a workgroup takes `waves` of them
+constexpr VariantDesc kEncode2Variants[] = {
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1", 2 * kWaveBytes5},   // 0
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5},   // 1
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5},  // 2
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5},  // 3
+    {"wave-tiled 1 word/lane, 1 wave/wg, ld=nt st=sc1 (tiles split cache lines)", kWaveBytes5},  // 4
+    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5},          // 5
+};
+constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
+
+constexpr VariantDesc kDecode2Variants[] = {
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5},   // 0
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5},   // 1
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5},  // 2
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5},  // 3
+    {"wave-tiled 1 word/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt (tiles split cache lines)", kWaveBytes5},  // 4
+    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5},                    // 5
+};
+constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
+
+// Whole wave tiles only; *done_words = words covered.
+template <bool STRICT>
+int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_words) {
+    if (variant < 0 || variant >= kNumEncode2Variants) return 1;
+    const uint64_t tile_nt = kEncode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
+    const uint64_t total = n_len / tile_nt;
+    *done_words = total * tile_words;
+    const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;  // wave tiles per launch (<= 2^31-1 threads)
+    for (uint64_t first = 0; first < total; first += per_launch) {
+        const uint64_t n = total - first < per_launch ? total - first : per_launch;
+        const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile_nt;
+        uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_words * 8;
+#define CNT_ENC2(W, P, L, S) \
+    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), 0, s, in, out, n)
+        switch (variant) {
+            case 0: CNT_ENC2(1, 2, kNT, kSC1); break;
+            case 1: CNT_ENC2(1, 4, kNT, kSC1); break;
+            case 2: CNT_ENC2(2, 2, kNT, kSC1); break;
+            case 3: CNT_ENC2(4, 2, kNT, kSC1); break;
+            case 4: CNT_ENC2(1, 1, kNT, kSC1); break;
+            case 5: CNT_ENC2(1, 2, 0, 0); break;
+            default: return 1;
+        }
+#undef CNT_ENC2
+    }
+    return 0;
+}
+
+inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_words) {
+    if (variant < 0 || variant >= kNumDecode2Variants) return 1;
+    const uint64_t tile_nt = kDecode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
+    const uint64_t total = len / tile_nt;
+    *done_words = total * tile_words;
+    const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
+    constexpr int kAll = kSC0 | kSC1 | kNT;
+    for (uint64_t first = 0; first < total; first += per_launch) {
+        const uint64_t n = total - first < per_launch ? total - first : per_launch;
+        const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * tile_words * 8;
+        uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_nt;
+#define CNT_DEC2(W, P, L, S) \
+    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), 0, s, in, out, n)
+        switch (variant) {
+            case 0: CNT_DEC2(1, 2, 0, kAll); break;
+            case 1: CNT_DEC2(1, 4, 0, kAll); break;
+            case 2: CNT_DEC2(2, 2, 0, kAll); break;
+            case 3: CNT_DEC2(4, 2, 0, kAll); break;
+            case 4: CNT_DEC2(1, 1, 0, kAll); break;
+            case 5: CNT_DEC2(1, 2, 0, 0); break;
+            default: return 1;
+        }
+#undef CNT_DEC2
+    }
+    return 0;
+}
+
+}  // namespace cnt

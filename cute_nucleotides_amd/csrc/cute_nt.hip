@@ -24,6 +24,7 @@
 #include "codec2_kernels.hpp"
 #include "codec2_launch.hpp"
 #include "codec5_kernels.hpp"
+#include "codec5_launch.hpp"
 #include "util_kernels.hpp"
 
 using namespace cnt;
@@ -45,6 +46,8 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // Index into kEncodeVariants / kDecodeVariants (codec2_launch.hpp); 0 = shipped default.
 std::atomic<int> g_encode_variant{0};
 std::atomic<int> g_decode_variant{0};
+std::atomic<int> g_encode2_variant{0};
+std::atomic<int> g_decode2_variant{0};
 
 // grid for the grid-stride kernels (5-letter codec): capped so grid x kBlock stays below
 // HIP's 2^31-1 total-thread limit; the kernels loop over the remaining tiles.
@@ -184,18 +187,11 @@ int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, un
     const bool strict = (flags & CNT_STRICT_LUT) != 0;
     uint64_t done_words = 0;
     if (aligned(d_n, 16)) {
-        const uint64_t n_tiles = n_len / kTileBytes5;
-        if (n_tiles) {
-            const unsigned g = grid_for(n_tiles);
-            if (strict)
-                hipLaunchKernelGGL((n_to_bits2_tiled<true>), dim3(g), dim3(kBlock), 0, s, static_cast<const u32x4*>(d_n),
-                                   static_cast<uint64_t*>(d_out), n_tiles);
-            else
-                hipLaunchKernelGGL((n_to_bits2_tiled<false>), dim3(g), dim3(kBlock), 0, s, static_cast<const u32x4*>(d_n),
-                                   static_cast<uint64_t*>(d_out), n_tiles);
-            HIP_TRY(hipGetLastError());
-            done_words = n_tiles * kWords5;
-        }
+        const int v = g_encode2_variant.load(std::memory_order_relaxed);
+        if (strict ? launch_encode2<true>(v, d_n, d_out, n_len, s, &done_words)
+                   : launch_encode2<false>(v, d_n, d_out, n_len, s, &done_words))
+            return CNT_EINVAL;
+        HIP_TRY(hipGetLastError());
     }
     if (done_words < words) {
         const unsigned g = generic_grid(words - done_words);
@@ -218,14 +214,8 @@ int decode2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsig
     const size_t used_words = cnt_words2_for(len);
     uint64_t done_words = 0;
     if (aligned(d_out, 16)) {
-        const uint64_t n_tiles = len / kTileBytes5;
-        if (n_tiles) {
-            hipLaunchKernelGGL(bits_to_n2_tiled, dim3(grid_for(n_tiles)),
-                               dim3(kBlock), 0, s, static_cast<const uint64_t*>(d_bits), static_cast<u32x4*>(d_out),
-                               n_tiles);
-            HIP_TRY(hipGetLastError());
-            done_words = n_tiles * kWords5;
-        }
+        if (launch_decode2(g_decode2_variant.load(std::memory_order_relaxed), d_bits, d_out, len, s, &done_words)) return CNT_EINVAL;
+        HIP_TRY(hipGetLastError());
     }
     if (done_words < used_words) {
         hipLaunchKernelGGL(bits_to_n2_generic, dim3(generic_grid(used_words - done_words)), dim3(kBlock), 0, s,
@@ -503,6 +493,12 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "decode")) {
         if (value < 0 || value >= kNumDecodeVariants) return CNT_EINVAL;
         g_decode_variant.store(value);
+    } else if (!strcmp(key, "encode2")) {
+        if (value < 0 || value >= kNumEncode2Variants) return CNT_EINVAL;
+        g_encode2_variant.store(value);
+    } else if (!strcmp(key, "decode2")) {
+        if (value < 0 || value >= kNumDecode2Variants) return CNT_EINVAL;
+        g_decode2_variant.store(value);
     } else {
         return CNT_EINVAL;
     }
@@ -513,8 +509,12 @@ int cnt_get_tuning(const char* key, int* value) {
     if (!key || !value) return CNT_EINVAL;
     if (!strcmp(key, "encode")) *value = g_encode_variant.load();
     else if (!strcmp(key, "decode")) *value = g_decode_variant.load();
+    else if (!strcmp(key, "encode2")) *value = g_encode2_variant.load();
+    else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
+    else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;
+    else if (!strcmp(key, "decode2_variants")) *value = kNumDecode2Variants;
     else return CNT_EINVAL;
     return CNT_OK;
 }
@@ -523,6 +523,8 @@ const char* cnt_tuning_name(const char* key, int value) {
     if (!key) return nullptr;
     if (!strcmp(key, "encode") && value >= 0 && value < kNumEncodeVariants) return kEncodeVariants[value].name;
     if (!strcmp(key, "decode") && value >= 0 && value < kNumDecodeVariants) return kDecodeVariants[value].name;
+    if (!strcmp(key, "encode2") && value >= 0 && value < kNumEncode2Variants) return kEncode2Variants[value].name;
+    if (!strcmp(key, "decode2") && value >= 0 && value < kNumDecode2Variants) return kDecode2Variants[value].name;
     return nullptr;
 }
 

@@ -122,8 +122,9 @@ int cnt_checksum_words_dev(const void *d_words, size_t first_word, size_t words,
 int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void *d_count, void *stream);
 
 /* Kernel-variant override for tuning / A-B runs (bench/ only; variant 0 is the shipped,
- * measured-best default).  key "encode" / "decode": value = variant index;
- * cnt_get_tuning also answers "encode_variants" / "decode_variants" (the counts).
+ * measured-best default).  key "encode" / "decode" (2-bit codec), "encode2" / "decode2"
+ * (5-letter codec): value = variant index; cnt_get_tuning also answers "<key>_variants"
+ * (the counts).
  * cnt_tuning_name returns the variant's description (NULL when out of range).
  * CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);

@@ -97,3 +97,31 @@ def test_large_round_trip(cn, oracle):
     m = 27 * 100000
     host = oracle.fill_random_acgtn(m, 11)
     assert np.array_equal(packed[: m // 27].cpu().numpy().view(np.uint64), oracle.n_to_bits2_lut(host))
+
+
+@pytest.mark.parametrize("key", ["encode2", "decode2"])
+def test_every_variant(cn, oracle, key):
+    import torch
+
+    from cute_nucleotides_amd import devutil
+
+    n_len = 1728 * 64 * 9 + 1728 * 3 + 11  # whole wave tiles for every workgroup width + a ragged rest
+    n = oracle.fill_random_acgtn(n_len, 21)
+    want = oracle.n_to_bits2_lut(n)
+    d = torch.from_numpy(n).cuda()
+    dbits = torch.from_numpy(want.view(np.int64)).cuda()
+    old = devutil.get_tuning(key)
+    assert old == 0
+    try:
+        for v, name in devutil.variants(key):
+            devutil.set_tuning(key, v)
+            if key == "encode2":
+                for strict in (False, True):
+                    got = cn.n_to_bits2_dev(d, strict_lut=strict).cpu().numpy().view(np.uint64)
+                    assert np.array_equal(got, want), (name, strict)
+            else:
+                for length in (n_len, n_len - 1, 1728 * 5, 1728 * 5 + 26):
+                    got = cn.bits_to_n2_dev(dbits, length).cpu().numpy()
+                    assert np.array_equal(got, oracle.bits_to_n2_lut(want, length)), (name, length)
+    finally:
+        devutil.set_tuning(key, old)
