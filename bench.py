@@ -151,14 +151,24 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Test hooks (never set by the driver): CNT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # CNT_BENCH_BACKEND=gloo swaps the process group's backend, so the N>1 code path can be
+    # exercised on a 1-GPU box (RCCL refuses two ranks on one device).
+    if os.environ.get("CNT_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("CNT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
 
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     import cute_nucleotides_amd as cn
     from cute_nucleotides_amd import devutil, sharding
@@ -201,7 +211,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -222,7 +232,7 @@ def main():
         got = d_packed[: want.size].cpu().numpy().view(np.uint64)
         ok = ok and bool(np.array_equal(got, want))
         ok = ok and devutil.checksum_words(d_packed[: want.size], first_word=lo // 32) == orc.checksum_words(want, first_word=lo // 32)
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verified = bool(flag.item())
