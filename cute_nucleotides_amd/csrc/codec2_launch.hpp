@@ -15,19 +15,20 @@ namespace cnt {
 struct VariantDesc {
     const char* name;
     uint32_t tile_nt;  // nucleotides per workgroup
+    uint32_t block;    // threads per workgroup (bounds the tiles one launch may cover)
 };
 
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
-    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1", 64 * 2 * 16},      // 0: default
-    {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16},              // 1
-    {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16},          // 2
-    {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16},               // 3: the first shape tried
-    {"lds B=256 U=4 ld=nt st=sc1", 256 * 4 * 16},                 // 4: LDS-widened stores
-    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16},                // 5: as 0 without the XCD pairing
-    {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16},              // 6
-    {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16},      // 7
-    {"stream B=256 U=4 plain", 256 * 4 * 16},                     // 8: no cache-policy bits at all
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1", 64 * 2 * 16, 64},      // 0: default
+    {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16, 256},              // 1
+    {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16, 512},          // 2
+    {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16, 256},               // 3: the first shape tried
+    {"lds B=256 U=4 ld=nt st=sc1", 256 * 4 * 16, 256},                 // 4: LDS-widened stores
+    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16, 64},                // 5: as 0 without the XCD pairing
+    {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16, 128},              // 6
+    {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16, 64},      // 7
+    {"stream B=256 U=4 plain", 256 * 4 * 16, 256},                     // 8: no cache-policy bits at all
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -47,7 +48,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
     const uint64_t tile = kEncodeVariants[variant].tile_nt;
     const uint64_t total_tiles = n_len / tile;
     *done_nt = total_tiles * tile;
-    const uint64_t per_launch = max_tiles_per_launch(512);  // 512 = the largest BLOCK below
+    const uint64_t per_launch = max_tiles_per_launch(kEncodeVariants[variant].block);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
     const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
     const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile;
@@ -74,15 +75,15 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
 
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
-    {"stream B=128 U=2 ld=plain st=sc0|sc1|nt", 128 * 2 * 16},        // 0: default
-    {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16},        // 1
-    {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16},  // 2
-    {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16},                   // 3: the first shape tried
-    {"lds B=256 U=4 ld=nt st=sc0|sc1|nt", 256 * 4 * 16},              // 4: LDS-widened loads
-    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 128 * 2 * 16},  // 5
-    {"stream B=128 U=2 ld=nt st=sc0|sc1|nt", 128 * 2 * 16},           // 6
-    {"stream B=128 U=2 ld=plain st=sc1|nt", 128 * 2 * 16},            // 7
-    {"stream B=256 U=4 plain", 256 * 4 * 16},                         // 8: no cache-policy bits at all
+    {"stream B=128 U=2 ld=plain st=sc0|sc1|nt", 128 * 2 * 16, 128},        // 0: default
+    {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16, 256},        // 1
+    {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16, 64},  // 2
+    {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16, 256},                   // 3: the first shape tried
+    {"lds B=256 U=4 ld=nt st=sc0|sc1|nt", 256 * 4 * 16, 256},              // 4: LDS-widened loads
+    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 128 * 2 * 16, 128},  // 5
+    {"stream B=128 U=2 ld=nt st=sc0|sc1|nt", 128 * 2 * 16, 128},           // 6
+    {"stream B=128 U=2 ld=plain st=sc1|nt", 128 * 2 * 16, 128},            // 7
+    {"stream B=256 U=4 plain", 256 * 4 * 16, 256},                         // 8: no cache-policy bits at all
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -91,7 +92,7 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     const uint64_t tile = kDecodeVariants[variant].tile_nt;
     const uint64_t total_tiles = len / tile;
     *done_nt = total_tiles * tile;
-    const uint64_t per_launch = max_tiles_per_launch(256);  // 256 = the largest BLOCK below
+    const uint64_t per_launch = max_tiles_per_launch(kDecodeVariants[variant].block);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
     const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
     const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * (tile / 4);

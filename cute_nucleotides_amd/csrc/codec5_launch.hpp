@@ -13,22 +13,22 @@ namespace cnt {
 
 // tile_nt = nucleotides per WAVE tile (WPL * 1728); a workgroup takes `waves` of them
 constexpr VariantDesc kEncode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1", 2 * kWaveBytes5},   // 0
-    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5},   // 1
-    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5},  // 2
-    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5},  // 3
-    {"wave-tiled 1 word/lane, 1 wave/wg, ld=nt st=sc1 (tiles split cache lines)", kWaveBytes5},  // 4
-    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5},          // 5
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64},   // 0
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5, 64},   // 1
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64},  // 2
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64},  // 3
+    {"wave-tiled 1 word/lane, 1 wave/wg, ld=nt st=sc1 (tiles split cache lines)", kWaveBytes5, 64},  // 4
+    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5, 64},          // 5
 };
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5},   // 0
-    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5},   // 1
-    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5},  // 2
-    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5},  // 3
-    {"wave-tiled 1 word/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt (tiles split cache lines)", kWaveBytes5},  // 4
-    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5},                    // 5
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64},   // 0
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64},   // 1
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64},  // 2
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64},  // 3
+    {"wave-tiled 1 word/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt (tiles split cache lines)", kWaveBytes5, 64},  // 4
+    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5, 64},                    // 5
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 

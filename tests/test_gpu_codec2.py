@@ -331,9 +331,11 @@ def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda):
     chunk_nt = 16 << 20
     chunk_w = chunk_nt // 32
     n_chunks = n_len // chunk_nt
-    # chunks around the launch split points (2^31-1 threads / 64 = 33554368 tiles of 2 KiB) and the ends
-    split_nt = ((0x7FFFFFFF // 512) // 64) * 64 * 2048
-    picks = {0, n_chunks - 1, split_nt // chunk_nt - 1, split_nt // chunk_nt, min(n_chunks - 1, 2 * split_nt // chunk_nt)}
+    # chunks around the launch split point ((2^31-1) / 64 threads -> 33554368 tiles of 2 KiB, i.e. the
+    # second launch covers only the last 64 tiles of the 2^36-nt buffer) and the ends
+    split_nt = ((0x7FFFFFFF // 64) // 64) * 64 * 2048
+    assert 0 < n_len - split_nt < chunk_nt
+    picks = {0, 1, n_chunks // 2, n_chunks - 2, n_chunks - 1}
     for c in sorted(picks):
         host_n = oracle.fill_random_acgt(chunk_nt, 0xBEEF, first_nt=c * chunk_nt)
         want = oracle.n_to_bits_lut(host_n)
