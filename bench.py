@@ -125,8 +125,23 @@ def cpu_baseline(seconds):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
+    # reference-faithful rows: the reference's own bench input ("ATCG" x 10000, cache-resident), one
+    # thread, output allocated inside every timed call (benches/bench_n_to_bits.rs:6-13) -- GiB/s of
+    # nucleotides like criterion prints them, to sit beside README.md:344-366 (i9-9880H)
+    n40 = np.frombuffer(b"ATCG" * 10000, dtype=np.uint8).copy()
+    b40 = np.empty(1250, dtype=np.uint64)
+    L.cnt_oracle_n_to_bits_lut(n40.ctypes.data, 40000, b40.ctypes.data, 1250)
+    names = {0: "n_to_bits_lut", 1: "n_to_bits_pext", 2: "n_to_bits_shift", 3: "n_to_bits_movemask", 4: "n_to_bits_mul",
+             5: "memcpy", 10: "bits_to_n_lut", 11: "bits_to_n_shuffle", 12: "bits_to_n_pdep", 13: "bits_to_n_clmul"}
+    faithful = {}
+    for fn, name in names.items():
+        src = n40 if fn < 10 else b40
+        L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, 40000, 2000)  # warm-up
+        per = L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, 40000, 20000 if fn not in (0, 10) else 4000)
+        faithful[name] = round(40000 / per / 2**30, 3)
     both = lambda e, d: 2.0 / (1.0 / e + 1.0 / d)  # nt converted per second over an encode pass + a decode pass
     return {
+        "reference_faithful_40k_GiBs": faithful,
         "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
         "sample": "%d Mi random ACGT nt (%d threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
                   "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"

@@ -76,6 +76,12 @@ int cnt_port_bits_to_n_clmul(const uint64_t *bits, size_t words, size_t len, uin
 int cnt_port_n_to_bits2_pext(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words);
 int cnt_port_bits_to_n2_pdep(const uint64_t *bits, size_t words, size_t len, uint8_t *out);
 
+/* Reference-faithful timing: seconds per call with the output malloc'ed and freed
+ * INSIDE the timed call, as benches/bench_n_to_bits.rs:6-7 demands.
+ * fn: 0 lut 1 pext 2 shift 3 movemask 4 mul 5 memcpy (in = ASCII, n_len nt)
+ *     10 lut 11 shuffle 12 pdep 13 clmul       (in = packed words, n_len nt) */
+double cnt_port_time_alloc_inclusive(int fn, const void *in, size_t n_len, int iters);
+
 /* ---- shared synthetic-input generator + checksum --------------------------- */
 /* Counter-based uniform {A,C,G,T}: block w (32 nt) draws r = splitmix64(seed +
  * w*0x9E3779B97F4A7C15) and emits "ACGT"[(r >> 2k) & 3] for k = 0..31.  The HIP

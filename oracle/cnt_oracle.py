@@ -69,6 +69,8 @@ def lib():
         L.cnt_oracle_words2_for.argtypes = [sz]
         L.cnt_oracle_words2_for.restype = sz
         L.cnt_port_cpu_ok.restype = ctypes.c_int
+        L.cnt_port_time_alloc_inclusive.argtypes = [ctypes.c_int, ctypes.c_void_p, sz, ctypes.c_int]
+        L.cnt_port_time_alloc_inclusive.restype = ctypes.c_double
         L.cnt_oracle_fill_random_acgt.argtypes = [u8p, sz, sz, ctypes.c_uint64]
         L.cnt_oracle_fill_random_acgt.restype = None
         L.cnt_oracle_fill_random_acgtn.argtypes = [u8p, sz, sz, ctypes.c_uint64]

@@ -290,3 +290,53 @@ CNT_SIMD int cnt_port_bits_to_n2_pdep(const uint64_t *bits, size_t words, size_t
     }
     return CNT_ORACLE_OK;
 }
+
+/* ---- reference-faithful timing row -------------------------------------------
+ * benches/bench_n_to_bits.rs:6-7: "all functions must allocate memory for its
+ * output data" -- every timed call of the reference allocates (and drops) its
+ * result.  This helper times `iters` calls of one function with malloc/free of
+ * the output inside the timed region and returns seconds per call, so bench.py
+ * can print rows that sit beside README.md:344-366 (40 000 nt, one thread).
+ * fn: 0 lut 1 pext 2 shift 3 movemask 4 mul 5 memcpy | 10 lut 11 shuffle 12 pdep 13 clmul */
+#include <stdlib.h>
+#include <time.h>
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double cnt_port_time_alloc_inclusive(int fn, const void *in, size_t n_len, int iters) {
+    typedef int (*enc_t)(const uint8_t *, size_t, uint64_t *, size_t);
+    typedef int (*dec_t)(const uint64_t *, size_t, size_t, uint8_t *);
+    static const enc_t encs[5] = {cnt_oracle_n_to_bits_lut, cnt_port_n_to_bits_pext, cnt_port_n_to_bits_shift,
+                                  cnt_port_n_to_bits_movemask, cnt_port_n_to_bits_mul};
+    static const dec_t decs[4] = {cnt_oracle_bits_to_n_lut, cnt_port_bits_to_n_shuffle, cnt_port_bits_to_n_pdep,
+                                  cnt_port_bits_to_n_clmul};
+    const size_t words = cnt_oracle_words_for(n_len);
+    volatile uint64_t sink = 0;
+    double t0 = now_s();
+    for (int i = 0; i < iters; i++) {
+        if (fn >= 0 && fn < 5) {
+            uint64_t *out = (uint64_t *)malloc(words * 8 + 8);
+            encs[fn]((const uint8_t *)in, n_len, out, words);
+            sink += out[words - 1];
+            free(out);
+        } else if (fn == 5) {
+            uint8_t *out = (uint8_t *)malloc(n_len);
+            memcpy(out, in, n_len);
+            sink += out[n_len - 1];
+            free(out);
+        } else if (fn >= 10 && fn < 14) {
+            uint8_t *out = (uint8_t *)aligned_alloc(32, words * 32);
+            decs[fn - 10]((const uint64_t *)in, words, n_len, out);
+            sink += out[n_len - 1];
+            free(out);
+        } else {
+            return -1.0;
+        }
+    }
+    (void)sink;
+    return (now_s() - t0) / (double)iters;
+}
