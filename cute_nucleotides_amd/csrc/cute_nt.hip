@@ -15,9 +15,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -58,12 +61,96 @@ inline unsigned generic_grid(uint64_t items) {
     return (unsigned)std::min<uint64_t>(std::max<uint64_t>(b, 1), 1u << 16);
 }
 
-// ---- per-thread device context (stream + grow-only scratch) ----------------------
+// ---- per-thread host-copy helpers ---------------------------------------------------
+// The host tier stages caller memory through pinned buffers (measured on MI355X / PCIe Gen5,
+// profiles/r01_host_tier_lab.log: pageable hipMemcpyAsync runs at 43 GB/s only after the runtime
+// has pinned the caller's pages and at 8-14 GB/s on first touch; explicit staging is 20-25 GB/s
+// with one copying thread and ~40 GB/s with four, cold or warm).  A tiny fork-join pool does the
+// staging copies; CNT_HOST_COPY_THREADS (default 4, 1 = no helpers) sizes it.
+class CopyPool {
+   public:
+    ~CopyPool() { stop(); }
+    void copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+        const size_t kMinPar = (size_t)2 << 20;
+        if (bytes < kMinPar || threads() <= 1) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const int T = threads();
+        const size_t per = ((bytes + T - 1) / T + 4095) / 4096 * 4096;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (int k = 1; k < T; ++k) {
+                const size_t lo = std::min(bytes, per * k), hi = std::min(bytes, per * (k + 1));
+                if (hi > lo) {
+                    jobs_.push_back({dst + lo, src + lo, hi - lo});
+                    ++pending_;
+                }
+            }
+        }
+        cv_work_.notify_all();
+        memcpy(dst, src, std::min(bytes, per));
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto& t : workers_) t.join();
+        workers_.clear();
+        stop_ = false;
+        started_ = false;
+    }
+
+   private:
+    struct Job {
+        uint8_t* d;
+        const uint8_t* s;
+        size_t n;
+    };
+    int threads() {
+        if (!started_) {
+            started_ = true;
+            int t = 4;
+            if (const char* e = getenv("CNT_HOST_COPY_THREADS")) t = atoi(e);
+            n_threads_ = std::max(1, std::min(t, 16));
+            for (int k = 1; k < n_threads_; ++k) workers_.emplace_back([this] { run(); });
+        }
+        return n_threads_;
+    }
+    void run() {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+            if (stop_) return;
+            Job j = jobs_.back();
+            jobs_.pop_back();
+            lk.unlock();
+            memcpy(j.d, j.s, j.n);
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<Job> jobs_;
+    std::vector<std::thread> workers_;
+    size_t pending_ = 0;
+    int n_threads_ = 1;
+    bool stop_ = false, started_ = false;
+};
+
+// ---- per-thread device context (streams + grow-only device scratch + pinned staging) ----
 struct DevCtx {
     int device = -1;
     hipStream_t stream[2] = {nullptr, nullptr};
     void* d_in[2] = {nullptr, nullptr};
     void* d_out[2] = {nullptr, nullptr};
+    uint8_t* h_in[2] = {nullptr, nullptr};   // pinned
+    uint8_t* h_out[2] = {nullptr, nullptr};  // pinned
     size_t cap_in = 0, cap_out = 0;
 
     int ensure(size_t need_in, size_t need_out) {
@@ -72,16 +159,22 @@ struct DevCtx {
         if (need_in > cap_in) {
             for (int i = 0; i < 2; ++i) {
                 if (d_in[i]) HIP_TRY(hipFree(d_in[i]));
+                if (h_in[i]) HIP_TRY(hipHostFree(h_in[i]));
                 d_in[i] = nullptr;
+                h_in[i] = nullptr;
                 HIP_TRY(hipMalloc(&d_in[i], need_in));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_in[i]), need_in, hipHostMallocDefault));
             }
             cap_in = need_in;
         }
         if (need_out > cap_out) {
             for (int i = 0; i < 2; ++i) {
                 if (d_out[i]) HIP_TRY(hipFree(d_out[i]));
+                if (h_out[i]) HIP_TRY(hipHostFree(h_out[i]));
                 d_out[i] = nullptr;
+                h_out[i] = nullptr;
                 HIP_TRY(hipMalloc(&d_out[i], need_out));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_out[i]), need_out, hipHostMallocDefault));
             }
             cap_out = need_out;
         }
@@ -96,8 +189,11 @@ struct DevCtx {
                 if (stream[i]) (void)hipStreamDestroy(stream[i]);
                 if (d_in[i]) (void)hipFree(d_in[i]);
                 if (d_out[i]) (void)hipFree(d_out[i]);
+                if (h_in[i]) (void)hipHostFree(h_in[i]);
+                if (h_out[i]) (void)hipHostFree(h_out[i]);
                 stream[i] = nullptr;
                 d_in[i] = d_out[i] = nullptr;
+                h_in[i] = h_out[i] = nullptr;
             }
         }
         cap_in = cap_out = 0;
@@ -107,7 +203,9 @@ struct DevCtx {
 
 struct ThreadCtx {
     std::map<int, DevCtx> per_device;
+    CopyPool pool;
     ~ThreadCtx() {
+        pool.stop();
         for (auto& kv : per_device) kv.second.release();
     }
     int get(DevCtx** out) {
@@ -122,10 +220,10 @@ struct ThreadCtx {
 };
 thread_local ThreadCtx t_ctx;
 
-// Host-tier chunking: 64 Mi nucleotides per chunk keeps the scratch at
-// 2 x (64 MiB + 16 MiB) per thread while each chunk is ~1 ms of PCIe time.
-constexpr size_t kChunkNt = (size_t)64 << 20;  // multiple of 32 and of 27*... (see below for codec5)
-constexpr size_t kChunkNt5 = (size_t)27 * 2 << 20;  // 27-nt words: 2 Mi words per chunk
+// Host-tier chunking: 16 Mi nucleotides per chunk = ~0.4 ms of PCIe time per chunk, 2 x (16 + 16)
+// MiB of pinned staging and as much device scratch per calling thread.
+constexpr size_t kChunkNt = (size_t)16 << 20;       // multiple of 32
+constexpr size_t kChunkNt5 = (size_t)27 * 512 << 10;  // 27-nt words: 512 Ki words per chunk (13.5 Mi nt)
 
 // ---- device-tier bodies (shared by every tier) ------------------------------------
 int encode_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, hipStream_t s) {
@@ -242,22 +340,38 @@ int host_encode(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words,
     CNT_TRY(t_ctx.get(&c));
     const size_t chunk = std::min(chunk_nt, (n_len + unit_nt - 1) / unit_nt * unit_nt);
     CNT_TRY(c->ensure(chunk, chunk / unit_nt * 8));
+    // 2-slot pipeline: while slot A's H2D / kernel / D2H run on its stream, the host copies slot B's
+    // finished output to the caller and stages slot B's next input.
+    size_t pend_word[2] = {0, 0}, pend_words[2] = {0, 0};
+    uint8_t* out_bytes = reinterpret_cast<uint8_t*>(out);
+    auto retire = [&](int slot) -> int {
+        CNT_TRY(hip_rc(hipStreamSynchronize(c->stream[slot])));
+        if (pend_words[slot]) t_ctx.pool.copy(out_bytes + pend_word[slot] * 8, c->h_out[slot], pend_words[slot] * 8);
+        pend_words[slot] = 0;
+        return CNT_OK;
+    };
     size_t off = 0;
     int slot = 0, rc = CNT_OK;
     while (off < n_len && rc == CNT_OK) {
         const size_t m = std::min(chunk, n_len - off);
         const size_t w = (m + unit_nt - 1) / unit_nt;
         hipStream_t s = c->stream[slot];
-        rc = hip_rc(hipStreamSynchronize(s));  // slot's previous D2H done before its buffers are reused
-        if (rc == CNT_OK) rc = hip_rc(hipMemcpyAsync(c->d_in[slot], n + off, m, hipMemcpyHostToDevice, s));
+        rc = retire(slot);
+        if (rc == CNT_OK) {
+            t_ctx.pool.copy(c->h_in[slot], n + off, m);
+            rc = hip_rc(hipMemcpyAsync(c->d_in[slot], c->h_in[slot], m, hipMemcpyHostToDevice, s));
+        }
         if (rc == CNT_OK) rc = fn(c->d_in[slot], m, c->d_out[slot], w, flags, s);
-        if (rc == CNT_OK)
-            rc = hip_rc(hipMemcpyAsync(out + off / unit_nt, c->d_out[slot], w * 8, hipMemcpyDeviceToHost, s));
+        if (rc == CNT_OK) rc = hip_rc(hipMemcpyAsync(c->h_out[slot], c->d_out[slot], w * 8, hipMemcpyDeviceToHost, s));
+        if (rc == CNT_OK) {
+            pend_word[slot] = off / unit_nt;
+            pend_words[slot] = w;
+        }
         off += m;
         slot ^= 1;
     }
-    for (int i = 0; i < 2; ++i) {
-        int r2 = hip_rc(hipStreamSynchronize(c->stream[i]));
+    for (int i = 0; i < 2; ++i, slot ^= 1) {
+        int r2 = retire(slot);
         if (rc == CNT_OK) rc = r2;
     }
     return rc;
@@ -271,25 +385,39 @@ int host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, si
     DevCtx* c = nullptr;
     CNT_TRY(t_ctx.get(&c));
     const size_t chunk = std::min(chunk_nt, (len + unit_nt - 1) / unit_nt * unit_nt);
-    // +32: the reference's SIMD decoders may store whole 32-B blocks; ours never
-    // writes past `len`, the slack only keeps device stores inside the scratch.
+    // +32: the reference's SIMD decoders may store whole 32-B blocks; ours never writes past
+    // `len`, the slack only keeps device stores inside the scratch.
     CNT_TRY(c->ensure(chunk / unit_nt * 8, chunk + 32));
+    size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
+    const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(bits);
+    auto retire = [&](int slot) -> int {
+        CNT_TRY(hip_rc(hipStreamSynchronize(c->stream[slot])));
+        if (pend_n[slot]) t_ctx.pool.copy(out + pend_off[slot], c->h_out[slot], pend_n[slot]);
+        pend_n[slot] = 0;
+        return CNT_OK;
+    };
     size_t off = 0;
     int slot = 0, rc = CNT_OK;
     while (off < len && rc == CNT_OK) {
         const size_t m = std::min(chunk, len - off);
         const size_t w = (m + unit_nt - 1) / unit_nt;
         hipStream_t s = c->stream[slot];
-        rc = hip_rc(hipStreamSynchronize(s));
-        if (rc == CNT_OK)
-            rc = hip_rc(hipMemcpyAsync(c->d_in[slot], bits + off / unit_nt, w * 8, hipMemcpyHostToDevice, s));
+        rc = retire(slot);
+        if (rc == CNT_OK) {
+            t_ctx.pool.copy(c->h_in[slot], in_bytes + off / unit_nt * 8, w * 8);
+            rc = hip_rc(hipMemcpyAsync(c->d_in[slot], c->h_in[slot], w * 8, hipMemcpyHostToDevice, s));
+        }
         if (rc == CNT_OK) rc = fn(c->d_in[slot], w, m, c->d_out[slot], 0, s);
-        if (rc == CNT_OK) rc = hip_rc(hipMemcpyAsync(out + off, c->d_out[slot], m, hipMemcpyDeviceToHost, s));
+        if (rc == CNT_OK) rc = hip_rc(hipMemcpyAsync(c->h_out[slot], c->d_out[slot], m, hipMemcpyDeviceToHost, s));
+        if (rc == CNT_OK) {
+            pend_off[slot] = off;
+            pend_n[slot] = m;
+        }
         off += m;
         slot ^= 1;
     }
-    for (int i = 0; i < 2; ++i) {
-        int r2 = hip_rc(hipStreamSynchronize(c->stream[i]));
+    for (int i = 0; i < 2; ++i, slot ^= 1) {
+        int r2 = retire(slot);
         if (rc == CNT_OK) rc = r2;
     }
     return rc;
@@ -353,6 +481,7 @@ int cnt_get_device(int* device) {
 }
 
 int cnt_shutdown(void) {
+    t_ctx.pool.stop();
     for (auto& kv : t_ctx.per_device) kv.second.release();
     t_ctx.per_device.clear();
     return CNT_OK;
