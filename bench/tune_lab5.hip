@@ -1,0 +1,109 @@
+// tune_lab5.hip -- does limiting residency help?  (bench only)  The shipped stream kernels with a
+// dummy LDS allocation that caps the number of resident workgroups per CU (160 KiB / LDS bytes),
+// i.e. fewer tiles in flight = a tighter address window, at the cost of latency hiding.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o bench/tune_lab5 bench/tune_lab5.hip
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../cute_nucleotides_amd/csrc/codec2_kernels.hpp"
+#include "../cute_nucleotides_amd/csrc/util_kernels.hpp"
+
+using namespace cnt;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void enc_cap(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    extern __shared__ uint32_t pad[];
+    constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t tid = threadIdx.x;
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + tid) * 16, 0, LAUX));
+    if (n_tiles == 0xFFFFFFFFFFFFFFFFull) pad[tid] = v[0].x;  // keeps the allocation alive, never taken
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b32(enc16<false>(v[u]), rout, (u * BLOCK + tid) * 4, 0, SAUX);
+}
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void dec_cap(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    extern __shared__ uint32_t pad[];
+    constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t tid = threadIdx.x;
+    uint32_t x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (u * BLOCK + tid) * 4, 0, LAUX);
+    if (n_tiles == 0xFFFFFFFFFFFFFFFFull) pad[tid] = x[0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
+}
+
+struct Variant { std::string name; std::function<void(hipStream_t)> launch; std::vector<float> ms; bool is_enc; };
+static uint8_t *d_in, *d_packed, *d_out;
+static uint64_t N;
+static std::vector<Variant> vs;
+
+template <int B, int U, int C, int L, int S> void add_enc(int wg_per_cu) {
+    char n[96]; snprintf(n, 96, "enc B=%-4d U=%d C=%d cap %2d wg/CU", B, U, C, wg_per_cu); uint64_t t = N / (B * U * 16);
+    size_t lds = wg_per_cu >= 32 ? 0 : (size_t)(160 * 1024 / wg_per_cu) / 256 * 256;
+    CK(hipFuncSetAttribute((const void*)enc_cap<B, U, C, L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((enc_cap<B, U, C, L, S>), dim3((unsigned)t), dim3(B), lds, s, d_in, d_packed, t); }, {}, true}); }
+template <int B, int U, int C, int L, int S> void add_dec(int wg_per_cu) {
+    char n[96]; snprintf(n, 96, "dec B=%-4d U=%d C=%d cap %2d wg/CU", B, U, C, wg_per_cu); uint64_t t = N / (B * U * 16);
+    size_t lds = wg_per_cu >= 32 ? 0 : (size_t)(160 * 1024 / wg_per_cu) / 256 * 256;
+    CK(hipFuncSetAttribute((const void*)dec_cap<B, U, C, L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((dec_cap<B, U, C, L, S>), dim3((unsigned)t), dim3(B), lds, s, d_packed, d_out, t); }, {}, false}); }
+
+static uint64_t checksum(const void* p, uint64_t words, hipStream_t s) {
+    static unsigned long long* d_sum = nullptr;
+    if (!d_sum) CK(hipMalloc(&d_sum, 8));
+    CK(hipMemsetAsync(d_sum, 0, 8, s));
+    hipLaunchKernelGGL(checksum_words, dim3(4096), dim3(kBlock), 0, s, static_cast<const uint64_t*>(p), (uint64_t)0, words, d_sum);
+    unsigned long long h = 0; CK(hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); return h;
+}
+
+int main(int argc, char** argv) {
+    const int log2 = argc > 1 ? atoi(argv[1]) : 34, rounds = argc > 2 ? atoi(argv[2]) : 5, iters = argc > 3 ? atoi(argv[3]) : 2;
+    N = 1ull << log2;
+    CK(hipMalloc(&d_in, N)); CK(hipMalloc(&d_packed, N / 4)); CK(hipMalloc(&d_out, N));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipLaunchKernelGGL(fill_random_acgt, dim3(1 << 16), dim3(kBlock), 0, s, d_in, (uint64_t)0, N, (uint64_t)0x5EED, 1);
+    CK(hipStreamSynchronize(s));
+    for (int k : {32, 28, 26, 25, 24, 23, 22, 20}) { add_enc<64, 2, 2, 2, 16>(k); add_enc<64, 2, 1, 2, 16>(k); }
+    for (int k : {32, 7, 6, 5}) { add_enc<256, 1, 1, 2, 16>(k); }
+    for (int k : {32, 14, 12, 11, 10}) { add_enc<128, 2, 1, 2, 16>(k); add_enc<128, 1, 2, 2, 16>(k); }
+    for (int k : {32, 16, 14, 13, 12, 11}) { add_dec<128, 2, 1, 0, 19>(k); add_dec<128, 2, 2, 0, 19>(k); }
+    for (int k : {32, 28, 24, 22, 20}) { add_dec<64, 2, 2, 0, 19>(k); add_dec<64, 2, 1, 0, 19>(k); }
+    uint64_t ref_enc = 0, ref_dec = 0; bool he = false, hd = false;
+    hipLaunchKernelGGL((n_to_bits_stream<256, 4, 1, 0, 0, false>), dim3((unsigned)(N / 16384)), dim3(256), 0, s, d_in, d_packed, N / 16384);
+    for (auto& v : vs) {
+        if (v.is_enc) CK(hipMemsetAsync(d_packed, 0xFF, 1 << 20, s)); else CK(hipMemsetAsync(d_out, 0xFF, 1 << 20, s));
+        v.launch(s); CK(hipGetLastError());
+        uint64_t c = v.is_enc ? checksum(d_packed, N / 32, s) : checksum(d_out, N / 8, s);
+        uint64_t& ref = v.is_enc ? ref_enc : ref_dec; bool& have = v.is_enc ? he : hd;
+        if (!have) { ref = c; have = true; }
+        if (c != ref) { fprintf(stderr, "MISMATCH %s\n", v.name.c_str()); return 2; }
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < iters; ++i) v.launch(s);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); v.ms.push_back(ms / iters);
+        }
+    for (auto& v : vs) { std::sort(v.ms.begin(), v.ms.end());
+        printf("%-40s %8.4f ms (min %8.4f)  %7.1f GB/s\n", v.name.c_str(), (double)v.ms[v.ms.size() / 2], (double)v.ms[0], 1.25 * N / v.ms[v.ms.size() / 2] / 1e6); }
+    return 0;
+}

@@ -16,19 +16,25 @@ struct VariantDesc {
     const char* name;
     uint32_t tile_nt;  // nucleotides per workgroup
     uint32_t block;    // threads per workgroup (bounds the tiles one launch may cover)
+    uint32_t wg_cap;   // resident workgroups per CU to aim for via a dummy LDS allocation (0 = no cap)
 };
+
+// dynamic-LDS bytes that let `cap` workgroups (and no more) fit in a CU's 160 KiB
+inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (163840u / cap) / 256u * 256u : 0u; }
 
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
-    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1", 64 * 2 * 16, 64},      // 0: default
-    {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16, 256},              // 1
-    {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16, 512},          // 2
-    {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16, 256},               // 3: the first shape tried
-    {"lds B=256 U=4 ld=nt st=sc1", 256 * 4 * 16, 256},                 // 4: LDS-widened stores
-    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16, 64},                // 5: as 0 without the XCD pairing
-    {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16, 128},              // 6
-    {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16, 64},      // 7
-    {"stream B=256 U=4 plain", 256 * 4 * 16, 256},                     // 8: no cache-policy bits at all
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 0: default
+    {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16, 256, 0},              // 1
+    {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16, 512, 0},          // 2
+    {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16, 256, 0},               // 3: the first shape tried
+    {"lds B=256 U=4 ld=nt st=sc1", 256 * 4 * 16, 256, 0},                 // 4: LDS-widened stores
+    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16, 64, 0},                // 5: as 0 without the XCD pairing
+    {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16, 128, 0},              // 6
+    {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16, 64, 0},      // 7
+    {"stream B=256 U=4 plain", 256 * 4 * 16, 256, 0},                     // 8: no cache-policy bits at all
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1 (no residency cap)", 64 * 2 * 16, 64, 0},  // 9: as 0, uncapped
+    {"stream B=128 U=2 ld=nt st=sc1, 10 wg/CU", 128 * 2 * 16, 128, 10},   // 10
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -54,8 +60,9 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
     const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile;
     uint8_t* out = static_cast<uint8_t*>(d_out) + first * (tile / 4);
     const dim3 g(grid_of(n_tiles));
+    const uint32_t lds = lds_for_cap(kEncodeVariants[variant].wg_cap);
 #define CNT_ENC_STREAM(B, U, C, L, S) \
-    hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), 0, s, in, out, n_tiles)
+    hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, n_tiles)
     switch (variant) {
         case 0: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
         case 1: CNT_ENC_STREAM(256, 1, 1, kNT, kSC1); break;
@@ -66,6 +73,8 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
         case 6: CNT_ENC_STREAM(128, 2, 1, kNT, kSC1); break;
         case 7: CNT_ENC_STREAM(64, 2, 4, kNT, kSC1); break;
         case 8: CNT_ENC_STREAM(256, 4, 1, 0, 0); break;
+        case 9: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
+        case 10: CNT_ENC_STREAM(128, 2, 1, kNT, kSC1); break;
         default: return 1;
     }
     }
@@ -75,15 +84,17 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
 
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
-    {"stream B=128 U=2 ld=plain st=sc0|sc1|nt", 128 * 2 * 16, 128},        // 0: default
-    {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16, 256},        // 1
-    {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16, 64},  // 2
-    {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16, 256},                   // 3: the first shape tried
-    {"lds B=256 U=4 ld=nt st=sc0|sc1|nt", 256 * 4 * 16, 256},              // 4: LDS-widened loads
-    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 128 * 2 * 16, 128},  // 5
-    {"stream B=128 U=2 ld=nt st=sc0|sc1|nt", 128 * 2 * 16, 128},           // 6
-    {"stream B=128 U=2 ld=plain st=sc1|nt", 128 * 2 * 16, 128},            // 7
-    {"stream B=256 U=4 plain", 256 * 4 * 16, 256},                         // 8: no cache-policy bits at all
+    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 0: default
+    {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16, 256, 0},        // 1
+    {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16, 64, 0},  // 2
+    {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16, 256, 0},                   // 3: the first shape tried
+    {"lds B=256 U=4 ld=nt st=sc0|sc1|nt", 256 * 4 * 16, 256, 0},              // 4: LDS-widened loads
+    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 128 * 2 * 16, 128, 0},  // 5
+    {"stream B=128 U=2 ld=nt st=sc0|sc1|nt", 128 * 2 * 16, 128, 0},           // 6
+    {"stream B=128 U=2 ld=plain st=sc1|nt", 128 * 2 * 16, 128, 0},            // 7
+    {"stream B=256 U=4 plain", 256 * 4 * 16, 256, 0},                         // 8: no cache-policy bits at all
+    {"stream B=128 U=2 ld=plain st=sc0|sc1|nt (no residency cap)", 128 * 2 * 16, 128, 0},  // 9: as 10, uncapped
+    {"stream B=128 U=2 ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 10: as 0 without the XCD pairing
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -99,10 +110,11 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile;
     const dim3 g(grid_of(n_tiles));
     constexpr int kAll = kSC0 | kSC1 | kNT;
+    const uint32_t lds = lds_for_cap(kDecodeVariants[variant].wg_cap);
 #define CNT_DEC_STREAM(B, U, C, L, S) \
-    hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), 0, s, in, out, n_tiles)
+    hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), lds, s, in, out, n_tiles)
     switch (variant) {
-        case 0: CNT_DEC_STREAM(128, 2, 1, 0, kAll); break;
+        case 0: CNT_DEC_STREAM(128, 2, 2, 0, kAll); break;
         case 1: CNT_DEC_STREAM(256, 2, 1, 0, kAll); break;
         case 2: CNT_DEC_STREAM(64, 2, 2, 0, kAll); break;
         case 3: CNT_DEC_STREAM(256, 2, 1, kNT, kNT); break;
@@ -111,6 +123,8 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 6: CNT_DEC_STREAM(128, 2, 1, kNT, kAll); break;
         case 7: CNT_DEC_STREAM(128, 2, 1, 0, kSC1 | kNT); break;
         case 8: CNT_DEC_STREAM(256, 4, 1, 0, 0); break;
+        case 9: CNT_DEC_STREAM(128, 2, 1, 0, kAll); break;
+        case 10: CNT_DEC_STREAM(128, 2, 1, 0, kAll); break;
         default: return 1;
     }
     }

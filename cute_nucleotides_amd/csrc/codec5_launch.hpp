@@ -13,22 +13,28 @@ namespace cnt {
 
 // tile_nt = nucleotides per WAVE tile (WPL * 1728); a workgroup takes `waves` of them
 constexpr VariantDesc kEncode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64},   // 0
-    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5, 64},   // 1
-    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64},  // 2
-    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64},  // 3
-    {"wave-tiled 1 word/lane, 1 wave/wg, ld=nt st=sc1 (tiles split cache lines)", kWaveBytes5, 64},  // 4
-    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5, 64},          // 5
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 0: default
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5, 64, 0},   // 1
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},  // 2
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},  // 3
+    {"wave-tiled 1 word/lane, 1 wave/wg, ld=nt st=sc1 (tiles split cache lines)", kWaveBytes5, 64, 0},  // 4
+    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5, 64, 0},          // 5
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},   // 6: as 0 without the residency cap
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 7
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 8
 };
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64},   // 0
-    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64},   // 1
-    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64},  // 2
-    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64},  // 3
-    {"wave-tiled 1 word/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt (tiles split cache lines)", kWaveBytes5, 64},  // 4
-    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5, 64},                    // 5
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 0: default
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64, 0},   // 1
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 2
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 3
+    {"wave-tiled 1 word/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt (tiles split cache lines)", kWaveBytes5, 64, 0},  // 4
+    {"wave-tiled 2 words/lane, 1 wave/wg, plain", 2 * kWaveBytes5, 64, 0},                    // 5
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},   // 6: as 0 without the residency cap
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 7
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 8
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -44,8 +50,9 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile_nt;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_words * 8;
+        const uint32_t lds = kEncode2Variants[variant].wg_cap ? lds_for_cap(kEncode2Variants[variant].wg_cap) - 3584u : 0u;  // slab is 3488 B static
 #define CNT_ENC2(W, P, L, S) \
-    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), 0, s, in, out, n)
+    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
             case 0: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 1: CNT_ENC2(1, 4, kNT, kSC1); break;
@@ -53,6 +60,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
             case 3: CNT_ENC2(4, 2, kNT, kSC1); break;
             case 4: CNT_ENC2(1, 1, kNT, kSC1); break;
             case 5: CNT_ENC2(1, 2, 0, 0); break;
+            case 6: case 7: case 8: CNT_ENC2(1, 2, kNT, kSC1); break;
             default: return 1;
         }
 #undef CNT_ENC2
@@ -71,8 +79,9 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * tile_words * 8;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_nt;
+        const uint32_t lds = kDecode2Variants[variant].wg_cap ? lds_for_cap(kDecode2Variants[variant].wg_cap) - 3584u : 0u;  // slab is 3488 B static
 #define CNT_DEC2(W, P, L, S) \
-    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), 0, s, in, out, n)
+    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
             case 0: CNT_DEC2(1, 2, 0, kAll); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
@@ -80,6 +89,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 3: CNT_DEC2(4, 2, 0, kAll); break;
             case 4: CNT_DEC2(1, 1, 0, kAll); break;
             case 5: CNT_DEC2(1, 2, 0, 0); break;
+            case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
             default: return 1;
         }
 #undef CNT_DEC2
