@@ -39,6 +39,14 @@ SIGNATURES = {
     "cnt_fill_random_acgtn_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),
     "cnt_checksum_words_dev": (_int, [_vp, _sz, _sz, _vp, _vp]),
     "cnt_count_mismatch_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "cnt_hamming_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "cnt_complement_dev": (_int, [_vp, _sz, _vp, _vp]),
+    "cnt_reverse_complement_dev": (_int, [_vp, _sz, _vp, _vp]),
+    "cnt_validate_dev": (_int, [_vp, _sz, _uint, _vp, _vp]),
+    "cnt_hamming": (_int, [_vp, _vp, _sz, ctypes.POINTER(_u64)]),
+    "cnt_complement": (_int, [_vp, _sz, _vp]),
+    "cnt_reverse_complement": (_int, [_vp, _sz, _vp]),
+    "cnt_validate": (_int, [_vp, _sz, _uint, ctypes.POINTER(_u64)]),
     "cnt_set_tuning": (_int, [ctypes.c_char_p, _int]),
     "cnt_get_tuning": (_int, [ctypes.c_char_p, ctypes.POINTER(_int)]),
     "cnt_tuning_name": (ctypes.c_char_p, [ctypes.c_char_p, _int]),

@@ -658,3 +658,5 @@ const char* cnt_tuning_name(const char* key, int value) {
 }
 
 }  // extern "C"
+
+#include "packed_ops_abi.inc"

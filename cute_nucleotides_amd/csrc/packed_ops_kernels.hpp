@@ -1,0 +1,172 @@
+// packed_ops_kernels.hpp -- operations on the 2-bit packed representation without decoding
+// (SURVEY 8 f-4).  The reference does not implement these: its README only points at them
+// ("Many operations (like Hamming distance) can be done directly on the bit strings without
+// decoding", README.md:45; links to complement / hamming / validity code in another project,
+// README.md:20-25) -- so there are no reference vectors and parity for this file is pinned
+// only by the definitions restated in oracle/cnt_oracle.c (see oracle/README.md).
+//
+// Layout as everywhere: nucleotide i = bits 2*(i&31).. of word i>>5, codes A0 C1 T2 G3.
+//   hamming            #{ i < len : code_a(i) != code_b(i) }
+//   complement         A<->T, C<->G = flip the high bit of every 2-bit code (x ^ 0xAAAA...)
+//   reverse complement out(i) = complement(in(len-1-i))
+//   validate           #{ bytes of an ASCII buffer outside ACGTUacgtu (optionally also N/n) }
+// All four are HBM streams; reductions use one no-return atomic per workgroup.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codec2_kernels.hpp"
+
+namespace cnt {
+
+constexpr int kRedBlock = 1024;  // reduction kernels: big workgroups, few atomics (read-only streams like them)
+
+__device__ __forceinline__ uint32_t diff_codes32(uint32_t a, uint32_t b) {  // # differing 2-bit codes in a dword
+    const uint32_t x = a ^ b;
+    return __builtin_popcount((x | (x >> 1)) & 0x55555555u);
+}
+
+__device__ __forceinline__ uint64_t block_sum_to(uint64_t v, unsigned long long* dst) {
+    // wave reduce -> LDS -> one no-return atomic per workgroup
+    __shared__ unsigned long long part[kRedBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t s = 0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) s += part[w];
+        if (s) (void)__hip_atomic_fetch_add(dst, (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return s;
+    }
+    return 0;
+}
+
+// Hamming distance over whole 16-B vectors (64 nt each); tile = kRedBlock*U vectors per workgroup.
+template <int U>
+__global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                           uint64_t n_tiles, unsigned long long* __restrict__ count) {
+    constexpr uint32_t TILE = kRedBlock * U * 16;
+    const uint64_t t = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + t * TILE, TILE), rb = rsrc_of(b + t * TILE, TILE);
+    u32x4 va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        va[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (u * kRedBlock + threadIdx.x) * 16, 0, kNT));
+        vb[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (u * kRedBlock + threadIdx.x) * 16, 0, kNT));
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        c += diff_codes32(va[u].x, vb[u].x) + diff_codes32(va[u].y, vb[u].y) + diff_codes32(va[u].z, vb[u].z) + diff_codes32(va[u].w, vb[u].w);
+    block_sum_to(c, count);
+}
+
+// generic / tail: one thread per word from first_word, last word masked to `len`
+__global__ __launch_bounds__(kRedBlock) void hamming_generic(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                                             uint64_t len, uint64_t first_word, uint64_t n_words,
+                                                             unsigned long long* __restrict__ count) {
+    uint64_t c = 0;
+    for (uint64_t w = first_word + blockIdx.x * (uint64_t)kRedBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kRedBlock) {
+        uint64_t x = a[w] ^ b[w];
+        const uint64_t rem = len - (w << 5);
+        if (rem < 32) x &= (1ull << (2 * rem)) - 1;
+        c += __builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
+    }
+    block_sum_to(c, count);
+}
+
+// complement: one thread per 16-B vector (whole vectors), stream shape of the codec kernels
+template <int BLOCK, int U>
+__global__ __launch_bounds__(BLOCK) void complement_tiles(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    constexpr uint32_t TILE = BLOCK * U * 16;
+    const uint64_t t = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE, TILE), rout = rsrc_of(out + t * TILE, TILE);
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + threadIdx.x) * 16, 0, kNT));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, v[u] ^ 0xAAAAAAAAu), rout, (u * BLOCK + threadIdx.x) * 16, 0, kSC0 | kSC1 | kNT);
+}
+
+__global__ __launch_bounds__(kBlock) void complement_generic(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t len,
+                                                             uint64_t first_word, uint64_t n_words) {
+    for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock) {
+        uint64_t x = in[w] ^ 0xAAAAAAAAAAAAAAAAull;
+        const uint64_t rem = len - (w << 5);
+        if (rem < 32) x &= (1ull << (2 * rem)) - 1;  // unused high bits stay zero, like every encoder's output
+        out[w] = x;
+    }
+}
+
+// reverse the order of the 32 two-bit codes of a word
+__device__ __forceinline__ uint64_t reverse_codes64(uint64_t x) {
+    x = __brevll(x);  // reverses bits: also swaps the two bits inside each code ...
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);  // ... swap them back
+}
+
+// reverse complement: output word w holds nt 32w..32w+31 = complement of input nt len-1-32w-k.
+// One thread per output word; each reads a 64-bit window that straddles two input words.
+__global__ __launch_bounds__(kBlock) void reverse_complement_words(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                   uint64_t len, uint64_t n_words) {
+    for (uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock) {
+        // input nts p_lo .. p_lo+31 with p_lo = len - 32 - 32w (may be negative for the last output word)
+        const int64_t p_lo = (int64_t)len - 32 - (int64_t)(w << 5);
+        uint64_t window;
+        if (p_lo >= 0) {
+            const uint64_t iw = (uint64_t)p_lo >> 5;
+            const unsigned sh = 2u * ((unsigned)p_lo & 31u);
+            window = in[iw] >> sh;
+            if (sh) window |= in[iw + 1] << (64 - sh);  // iw+1 <= (len-1)>>5 whenever sh != 0
+        } else {
+            window = in[0] << (2u * (unsigned)(-p_lo));  // the first -p_lo codes of the window do not exist
+        }
+        uint64_t x = reverse_codes64(window) ^ 0xAAAAAAAAAAAAAAAAull;
+        const uint64_t rem = len - (w << 5);
+        if (rem < 32) x &= (1ull << (2 * rem)) - 1;
+        out[w] = x;
+    }
+}
+
+// validity: count bytes outside the alphabet.  SWAR: zero byte in (x & 0xDF) ^ expect  <=> valid letter.
+template <bool ALLOW_N>
+__device__ __forceinline__ uint32_t invalid_bytes32(uint32_t x) {
+    const uint32_t exp_lo = 0x43FF41FFu;                             // k=0:FF 1:'A' 2:FF 3:'C'
+    const uint32_t exp_hi = ALLOW_N ? 0x474E5554u : 0x47FF5554u;     // k=4:'T' 5:'U' 6:'N'|FF 7:'G'
+    const uint32_t expect = __builtin_amdgcn_perm(exp_hi, exp_lo, x & 0x07070707u);
+    const uint32_t z = (x & 0xDFDFDFDFu) ^ expect;
+    const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+    return __builtin_popcount(nz);
+}
+
+template <int U, bool ALLOW_N>
+__global__ __launch_bounds__(kRedBlock) void validate_tiles(const uint8_t* __restrict__ n, uint64_t n_tiles,
+                                                            unsigned long long* __restrict__ count) {
+    constexpr uint32_t TILE = kRedBlock * U * 16;
+    const uint64_t t = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rn = rsrc_of(n + t * TILE, TILE);
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rn, (u * kRedBlock + threadIdx.x) * 16, 0, kNT));
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        c += invalid_bytes32<ALLOW_N>(v[u].x) + invalid_bytes32<ALLOW_N>(v[u].y) + invalid_bytes32<ALLOW_N>(v[u].z) + invalid_bytes32<ALLOW_N>(v[u].w);
+    block_sum_to(c, count);
+}
+
+template <bool ALLOW_N>
+__global__ __launch_bounds__(kRedBlock) void validate_generic(const uint8_t* __restrict__ n, uint64_t first, uint64_t n_len,
+                                                              unsigned long long* __restrict__ count) {
+    uint64_t c = 0;
+    for (uint64_t i = first + blockIdx.x * (uint64_t)kRedBlock + threadIdx.x; i < n_len; i += (uint64_t)gridDim.x * kRedBlock)
+        c += invalid_bytes32<ALLOW_N>(0x41414100u | n[i]);  // pad the other three lanes with 'A' (valid)
+    block_sum_to(c, count);
+}
+
+}  // namespace cnt

@@ -110,6 +110,28 @@ int cnt_bits_to_n_dev(const void *d_bits, size_t words, size_t len, void *d_out,
 int cnt_n_to_bits2_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *stream);
 int cnt_bits_to_n2_dev(const void *d_bits, size_t words, size_t len, void *d_out, unsigned flags, void *stream);
 
+/* ---- packed-domain operations ----------------------------------- */
+/* The reference does not implement these; its README points at them as the reason to keep
+ * data packed ("many operations (like Hamming distance) can be done directly on the bit
+ * strings without decoding", README.md:45; complement / hamming / validity links :20-25).
+ * Layout as above (32 nt per word, A0 C1 T2 G3).  `len` is in nucleotides; inputs hold
+ * ceil(len/32) words; bits beyond `len` in the last input word are ignored and written as
+ * zero.  Device tier: pointers are device memory, enqueue-only, counters are device u64
+ * that the caller zeroes (the call adds to them).  Host tier: synchronous.
+ *   hamming             #{ i < len : code_a(i) != code_b(i) }
+ *   complement          A<->T, C<->G
+ *   reverse_complement  out(i) = complement(in(len-1-i)); not in place
+ *   validate            #{ bytes outside ACGTUacgtu }, with CNT_ALLOW_N also N/n are legal */
+#define CNT_ALLOW_N 0x2u
+int cnt_hamming_dev(const void *d_a, const void *d_b, size_t len, void *d_count, void *stream);
+int cnt_complement_dev(const void *d_bits, size_t len, void *d_out, void *stream);
+int cnt_reverse_complement_dev(const void *d_bits, size_t len, void *d_out, void *stream);
+int cnt_validate_dev(const void *d_n, size_t n_len, unsigned flags, void *d_invalid_count, void *stream);
+int cnt_hamming(const uint64_t *a, const uint64_t *b, size_t len, uint64_t *distance);
+int cnt_complement(const uint64_t *bits, size_t len, uint64_t *out);
+int cnt_reverse_complement(const uint64_t *bits, size_t len, uint64_t *out);
+int cnt_validate(const uint8_t *n, size_t n_len, unsigned flags, uint64_t *invalid);
+
 /* ---- device utilities for benches and large-size verification ----------------- */
 /* Counter-based uniform {A,C,G,T} (resp. {A,C,G,T,N}, P(N)=1/16) generator,
  * identical to oracle/cnt_oracle.c's, so a host can regenerate any chunk.

@@ -181,3 +181,41 @@ uint64_t cnt_oracle_checksum_words(const uint64_t *w, size_t first_word, size_t 
     for (size_t i = 0; i < words; i++) s += fmix64(w[i] + (uint64_t)(first_word + i + 1) * CNT_GOLDEN);
     return s;
 }
+
+/* ---- packed-domain operations --------------------------------
+ * NOT in the reference (README.md:20-25,45 only link to other projects for them), so
+ * there are no reference vectors: parity for these four is pinned only by these
+ * definitions, written independently of the HIP kernels (scalar, one nucleotide at a
+ * time).  "parity unpinned" in the sense of the task statement. */
+static unsigned code_at(const uint64_t *bits, size_t i) { return (unsigned)((bits[i >> 5] >> ((i & 31) << 1)) & 3); }
+static void put_code(uint64_t *bits, size_t i, unsigned c) { bits[i >> 5] |= (uint64_t)c << ((i & 31) << 1); }
+
+uint64_t cnt_oracle_hamming(const uint64_t *a, const uint64_t *b, size_t len) {
+    uint64_t d = 0;
+    for (size_t i = 0; i < len; i++) d += code_at(a, i) != code_at(b, i);
+    return d;
+}
+
+/* A(0)<->T(2), C(1)<->G(3): code ^ 2 */
+void cnt_oracle_complement(const uint64_t *bits, size_t len, uint64_t *out) {
+    size_t words = cnt_oracle_words_for(len);
+    if (words) memset(out, 0, words * 8);
+    for (size_t i = 0; i < len; i++) put_code(out, i, code_at(bits, i) ^ 2u);
+}
+
+void cnt_oracle_reverse_complement(const uint64_t *bits, size_t len, uint64_t *out) {
+    size_t words = cnt_oracle_words_for(len);
+    if (words) memset(out, 0, words * 8);
+    for (size_t i = 0; i < len; i++) put_code(out, i, code_at(bits, len - 1 - i) ^ 2u);
+}
+
+uint64_t cnt_oracle_validate(const uint8_t *n, size_t n_len, int allow_n) {
+    uint64_t bad = 0;
+    for (size_t i = 0; i < n_len; i++) {
+        uint8_t c = n[i];
+        int ok = c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'U' || c == 'a' || c == 'c' || c == 'g' || c == 't' ||
+                 c == 'u' || (allow_n && (c == 'N' || c == 'n'));
+        bad += !ok;
+    }
+    return bad;
+}

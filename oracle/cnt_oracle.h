@@ -76,6 +76,13 @@ int cnt_port_bits_to_n_clmul(const uint64_t *bits, size_t words, size_t len, uin
 int cnt_port_n_to_bits2_pext(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words);
 int cnt_port_bits_to_n2_pdep(const uint64_t *bits, size_t words, size_t len, uint8_t *out);
 
+/* ---- packed-domain operations (NOT in the reference: parity unpinned) ----
+ * Scalar definitions, one nucleotide at a time; see include/cute_nt.h for the semantics. */
+uint64_t cnt_oracle_hamming(const uint64_t *a, const uint64_t *b, size_t len);
+void cnt_oracle_complement(const uint64_t *bits, size_t len, uint64_t *out);
+void cnt_oracle_reverse_complement(const uint64_t *bits, size_t len, uint64_t *out);
+uint64_t cnt_oracle_validate(const uint8_t *n, size_t n_len, int allow_n);
+
 /* Reference-faithful timing: seconds per call with the output malloc'ed and freed
  * INSIDE the timed call, as benches/bench_n_to_bits.rs:6-7 demands.
  * fn: 0 lut 1 pext 2 shift 3 movemask 4 mul 5 memcpy (in = ASCII, n_len nt)

@@ -69,6 +69,14 @@ def lib():
         L.cnt_oracle_words2_for.argtypes = [sz]
         L.cnt_oracle_words2_for.restype = sz
         L.cnt_port_cpu_ok.restype = ctypes.c_int
+        L.cnt_oracle_hamming.argtypes = [u64p, u64p, sz]
+        L.cnt_oracle_hamming.restype = ctypes.c_uint64
+        L.cnt_oracle_complement.argtypes = [u64p, sz, u64p]
+        L.cnt_oracle_complement.restype = None
+        L.cnt_oracle_reverse_complement.argtypes = [u64p, sz, u64p]
+        L.cnt_oracle_reverse_complement.restype = None
+        L.cnt_oracle_validate.argtypes = [u8p, sz, ctypes.c_int]
+        L.cnt_oracle_validate.restype = ctypes.c_uint64
         L.cnt_port_time_alloc_inclusive.argtypes = [ctypes.c_int, ctypes.c_void_p, sz, ctypes.c_int]
         L.cnt_port_time_alloc_inclusive.restype = ctypes.c_double
         L.cnt_oracle_fill_random_acgt.argtypes = [u8p, sz, sz, ctypes.c_uint64]
@@ -181,6 +189,32 @@ def bits_to_n_clmul(bits, length):
 
 def bits_to_n2_pdep(bits, length):
     return _decode("cnt_port_bits_to_n2_pdep", bits, length, len(bits) * 27 + 5)
+
+
+# ---- packed-domain operations (not in the reference; parity unpinned) --------------------
+def hamming(a, b, length):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    return int(lib().cnt_oracle_hamming(_ptr(a), _ptr(b), length))
+
+
+def complement(bits, length):
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    out = np.empty((length + 31) // 32, dtype=np.uint64)
+    lib().cnt_oracle_complement(_ptr(bits), length, _ptr(out))
+    return out
+
+
+def reverse_complement(bits, length):
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    out = np.empty((length + 31) // 32, dtype=np.uint64)
+    lib().cnt_oracle_reverse_complement(_ptr(bits), length, _ptr(out))
+    return out
+
+
+def validate(n, allow_n=False):
+    n = _as_u8(n)
+    return int(lib().cnt_oracle_validate(_ptr(n), n.size, 1 if allow_n else 0))
 
 
 # ---- generator + checksum ---------------------------------------------------------
