@@ -105,8 +105,12 @@ def main():
         what, kind, u, nt, g = c
         med, mn = statistics.median(times[c]), min(times[c])
         bpn = 1.25 if what != "probe" else pbytes[kind]
+        if what == "probe":
+            label = "%s u=%d nt=%d grid=%d" % (pname[kind], u, nt, g)
+        else:
+            label = "v%-2d %s" % (u, kind)
         rows.append({
-            "what": what, "kind": kind if what != "probe" else pname[kind], "unroll": u, "nt": nt, "grid": g,
+            "what": what, "kernel": label, "variant": u if what != "probe" else None,
             "ms_median": round(med, 4), "ms_min": round(mn, 4),
             "gnts_median": round(n / med / 1e6, 1), "total_GBs_median": round(bpn * n / med / 1e6, 1),
             "total_GBs_best": round(bpn * n / mn / 1e6, 1),
@@ -115,8 +119,8 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump({"log2_nt": args.log2_nt, "rounds": args.rounds, "iters": args.iters, "rows": rows}, open(args.out, "w"), indent=1)
     for r in rows:
-        print("%-7s %-52s v=%d nt=%d grid=%-5d  %8.4f ms (min %8.4f)  %8.1f Gnt/s  %7.1f GB/s" % (
-            r["what"], r["kind"], r["unroll"], r["nt"], r["grid"], r["ms_median"], r["ms_min"], r["gnts_median"], r["total_GBs_median"]))
+        print("%-7s %-66s %8.4f ms (min %8.4f)  %8.1f Gnt/s  %7.1f GB/s" % (
+            r["what"], r["kernel"], r["ms_median"], r["ms_min"], r["gnts_median"], r["total_GBs_median"]))
 
 
 if __name__ == "__main__":

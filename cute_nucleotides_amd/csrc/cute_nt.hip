@@ -52,10 +52,6 @@ std::atomic<int> g_decode_variant{0};
 std::atomic<int> g_encode2_variant{0};
 std::atomic<int> g_decode2_variant{0};
 
-// grid for the grid-stride kernels (5-letter codec): capped so grid x kBlock stays below
-// HIP's 2^31-1 total-thread limit; the kernels loop over the remaining tiles.
-inline unsigned grid_for(uint64_t n_tiles) { return (unsigned)std::min<uint64_t>(n_tiles, 0x7FFFFFFFull / kBlock); }
-
 inline unsigned generic_grid(uint64_t items) {
     uint64_t b = (items + kBlock - 1) / kBlock;
     return (unsigned)std::min<uint64_t>(std::max<uint64_t>(b, 1), 1u << 16);
