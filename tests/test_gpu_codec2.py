@@ -341,3 +341,49 @@ def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda):
         want = oracle.n_to_bits_lut(host_n)
         got = packed[c * chunk_w : (c + 1) * chunk_w].cpu().numpy().view(np.uint64)
         assert np.array_equal(got, want), c
+
+
+# ---- boundary behaviour of the C ABI -------------------------------------------------------
+def test_output_pointer_only_8_byte_aligned(cn, oracle, torch_cuda):
+    """u64 outputs need 8-B alignment; 16-B is only needed for the fast path."""
+    torch = torch_cuda
+    n = _rand_valid(100000 + 7, 123)
+    want = oracle.n_to_bits_lut(n)
+    buf = torch.full((want.size + 3,), -1, dtype=torch.int64, device="cuda")
+    out = buf[1:]  # data_ptr % 16 == 8
+    assert out.data_ptr() % 16 == 8
+    got = cn.n_to_bits_dev(torch.from_numpy(n).cuda(), out=out).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    assert int(buf[0].item()) == -1 and int(buf[want.size + 1].item()) == -1
+    bits = torch.from_numpy(want.view(np.int64)).cuda()
+    dbuf = torch.zeros(want.size + 1, dtype=torch.int64, device="cuda")
+    dbuf[1:].copy_(bits)
+    got = cn.bits_to_n_dev(dbuf[1:], n.size).cpu().numpy()  # input % 16 == 8
+    assert np.array_equal(got, oracle.bits_to_n_lut(want, n.size))
+
+
+def test_host_tier_is_thread_safe_and_survives_shutdown(cn, oracle):
+    import threading
+
+    from cute_nucleotides_amd import _lib
+
+    inputs = [_rand_valid(3_000_000 + 17 * k, k) for k in range(6)]
+    wants = [oracle.n_to_bits_lut(x) for x in inputs]
+    results = [None] * len(inputs)
+
+    def work(k):
+        for _ in range(3):
+            bits = cn.n_to_bits_hip(inputs[k])
+            back = cn.bits_to_n_hip(bits, inputs[k].size)
+            results[k] = (bits, back)
+        _lib.lib().cnt_shutdown()  # frees this thread's streams / scratch / copy helpers
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(inputs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for k, (bits, back) in enumerate(results):
+        assert np.array_equal(bits, wants[k])
+        assert bytes(back) == bytes(inputs[k]).upper().replace(b"U", b"T")
+    # the calling thread can shut down and keep going
+    assert _lib.lib().cnt_shutdown() == 0
+    assert np.array_equal(cn.n_to_bits_hip(inputs[0]), wants[0])
