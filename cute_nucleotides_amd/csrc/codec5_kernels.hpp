@@ -72,12 +72,22 @@ __device__ __forceinline__ uint64_t pack27(const uint32_t (&c)[7]) {
 // to 4 for the values 125..127 no encoder produces (reference reads past its
 // 5-entry LUT there; the oracle defines 'N').
 __device__ __forceinline__ uint32_t digits3(uint32_t v) {
-    uint32_t c = (v * 41u) >> 10;       // v/25 for v < 128 (checked in tests/test_bit_tricks.py)
-    uint32_t r = v - c * 25u;
-    uint32_t b = (r * 13u) >> 6;        // r/5 for r < 69
-    uint32_t a = r - b * 5u;
+    // all products fit 24 bits: v_mul_u32_u24 / v_mad_u32_u24 are full rate, v_mul_lo_u32 is not
+    uint32_t c = __umul24(v, 41u) >> 10;   // v/25 for v < 128 (checked in tests/test_bit_tricks.py)
+    uint32_t r = v - __umul24(c, 25u);
+    uint32_t b = __umul24(r, 13u) >> 6;    // r/5 for r < 69
+    uint32_t a = r - __umul24(b, 5u);
     c = c > 4u ? 4u : c;
     return a | (b << 8) | (c << 16);
+}
+
+// the nine 7-bit fields of a packed word held as two dwords, with 32-bit ops only:
+// fields 0..3 live in lo[0..27], field 4 straddles (lo[28..31], hi[0..2]), fields 5..8 in hi[3..30]
+template <int K>
+__device__ __forceinline__ uint32_t field7(uint32_t lo, uint32_t hi) {
+    if constexpr (K < 4) return __builtin_amdgcn_ubfe(lo, 7 * K, 7);
+    else if constexpr (K == 4) return __builtin_amdgcn_alignbit(hi, lo, 28) & 0x7Fu;
+    else return __builtin_amdgcn_ubfe(hi, 7 * K - 32, 7);
 }
 
 __device__ __forceinline__ uint32_t letters5(uint32_t codes /* 4 code bytes, each 0..4 */) {
@@ -152,7 +162,9 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
                                                                uint64_t n_wave_tiles) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
+    // access whose descriptor depends on it in a waterfall loop (v_readfirstlane / s_and_saveexec)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint64_t t = blockIdx.x * (uint64_t)WAVES + wave;
     if (t >= n_wave_tiles) return;  // wave-uniform
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, TILE_BYTES);
@@ -202,7 +214,9 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
                                                                uint64_t n_wave_tiles) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
+    // access whose descriptor depends on it in a waterfall loop (v_readfirstlane / s_and_saveexec)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint64_t t = blockIdx.x * (uint64_t)WAVES + wave;
     if (t >= n_wave_tiles) return;  // wave-uniform
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * (TILE_WORDS * 8), TILE_WORDS * 8);
@@ -214,10 +228,11 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
     for (int j = 0; j < WPL; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
 #pragma unroll
     for (int j = 0; j < WPL; ++j) {
-        const uint64_t word = ((uint64_t)w2[j][1] << 32) | w2[j][0];
+        const uint32_t lo = w2[j][0], hi = w2[j][1];
         uint32_t L[9];  // 3 letters per triplet in the low 24 bits
-#pragma unroll
-        for (int k = 0; k < 9; ++k) L[k] = letters5(digits3((uint32_t)(word >> (7 * k)) & 0x7Fu)) & 0x00FFFFFFu;
+#define CNT_L(K) L[K] = letters5(digits3(field7<K>(lo, hi))) & 0x00FFFFFFu
+        CNT_L(0); CNT_L(1); CNT_L(2); CNT_L(3); CNT_L(4); CNT_L(5); CNT_L(6); CNT_L(7); CNT_L(8);
+#undef CNT_L
         // the lane's 27 bytes as 7 dwords (b[6] holds 3 bytes), plus a zero guard
         uint32_t b[8];
         b[0] = L[0] | (L[1] << 24);
@@ -230,10 +245,13 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
         b[7] = 0;
         // window of 8 aligned dwords starting at dword (27*lane)>>2, bytes shifted left by the phase
         const uint32_t byte0 = 27u * lane, q0 = byte0 >> 2, s8 = (byte0 & 3u) * 8u;
+        // W = the 27-byte string shifted left by the phase: one v_alignbit_b32 per dword ({b[k],
+        // b[k-1]} >> (32 - s8)); a phase of 0 would need a shift of 32, which alignbit cannot do
         uint32_t W[8];
-        W[0] = (uint32_t)(((uint64_t)b[0] << s8));
+        const uint32_t sh = 32u - s8;
+        W[0] = b[0] << s8;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) W[k] = (uint32_t)(((((uint64_t)b[k] << 32) | b[k - 1]) << s8) >> 32);
+        for (int k = 1; k < 8; ++k) W[k] = s8 ? __builtin_amdgcn_alignbit(b[k], b[k - 1], sh) : b[k];
         // complete dwords this lane owns: q0 .. ((27*(lane+1))>>2) - 1 (6 or 7 of them); the
         // partial one after them belongs to lane+1, which receives it through the shuffle
         const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
