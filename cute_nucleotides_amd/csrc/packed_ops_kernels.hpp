@@ -10,7 +10,9 @@
 //   complement         A<->T, C<->G = flip the high bit of every 2-bit code (x ^ 0xAAAA...)
 //   reverse complement out(i) = complement(in(len-1-i))
 //   validate           #{ bytes of an ASCII buffer outside ACGTUacgtu (optionally also N/n) }
-// All four are HBM streams; reductions use one no-return atomic per workgroup.
+// All four are HBM streams.  Reductions write one partial sum per workgroup to a scratch array
+// and a one-workgroup second kernel adds them up: one atomic per workgroup on a single counter
+// made the Hamming kernel atomic-bound (5.4 -> 7.2 TB/s without them, bench/tune_lab7.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -47,9 +49,34 @@ __device__ __forceinline__ uint64_t block_sum_to(uint64_t v, unsigned long long*
 }
 
 // Hamming distance over whole 16-B vectors (64 nt each); tile = kRedBlock*U vectors per workgroup.
+// block_sum_to's sibling: the workgroup's sum goes to partial[blockIdx.x], no atomic
+__device__ __forceinline__ void block_sum_store(uint64_t v, unsigned long long* partial) {
+    __shared__ unsigned long long part2[kRedBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) part2[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t s = 0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) s += part2[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+// second pass: one workgroup adds n partial sums into *count (a single atomic)
+__global__ __launch_bounds__(kRedBlock) void sum_partials(const unsigned long long* __restrict__ partial, uint64_t n,
+                                                          unsigned long long* __restrict__ count) {
+    uint64_t s = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += kRedBlock) s += partial[i];
+    block_sum_to(s, count);
+}
+
 template <int U>
 __global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                                           uint64_t n_tiles, unsigned long long* __restrict__ count) {
+                                                           uint64_t n_tiles, unsigned long long* __restrict__ partial) {
     constexpr uint32_t TILE = kRedBlock * U * 16;
     const uint64_t t = blockIdx.x;
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + t * TILE, TILE), rb = rsrc_of(b + t * TILE, TILE);
@@ -63,7 +90,7 @@ __global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u)
         c += diff_codes32(va[u].x, vb[u].x) + diff_codes32(va[u].y, vb[u].y) + diff_codes32(va[u].z, vb[u].z) + diff_codes32(va[u].w, vb[u].w);
-    block_sum_to(c, count);
+    block_sum_store(c, partial);
 }
 
 // generic / tail: one thread per word from first_word, last word masked to `len`
@@ -146,7 +173,7 @@ __device__ __forceinline__ uint32_t invalid_bytes32(uint32_t x) {
 
 template <int U, bool ALLOW_N>
 __global__ __launch_bounds__(kRedBlock) void validate_tiles(const uint8_t* __restrict__ n, uint64_t n_tiles,
-                                                            unsigned long long* __restrict__ count) {
+                                                            unsigned long long* __restrict__ partial) {
     constexpr uint32_t TILE = kRedBlock * U * 16;
     const uint64_t t = blockIdx.x;
     const __amdgpu_buffer_rsrc_t rn = rsrc_of(n + t * TILE, TILE);
@@ -157,7 +184,7 @@ __global__ __launch_bounds__(kRedBlock) void validate_tiles(const uint8_t* __res
 #pragma unroll
     for (int u = 0; u < U; ++u)
         c += invalid_bytes32<ALLOW_N>(v[u].x) + invalid_bytes32<ALLOW_N>(v[u].y) + invalid_bytes32<ALLOW_N>(v[u].z) + invalid_bytes32<ALLOW_N>(v[u].w);
-    block_sum_to(c, count);
+    block_sum_store(c, partial);
 }
 
 template <bool ALLOW_N>
