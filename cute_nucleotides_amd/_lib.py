@@ -66,6 +66,15 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
+            # not built yet on this box: compile it (hipcc, gfx950) rather than give up -- this is
+            # still the HIP library, never a CPU substitute; without hipcc the import fails below
+            try:
+                from . import build as _build
+
+                _build.build()
+            except Exception as exc:  # noqa: BLE001
+                raise ImportError("%s is missing and could not be built: %s" % (LIB_PATH, exc)) from exc
+        if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s is missing: build it with `python -m cute_nucleotides_amd.build` "
                 "(or __graft_entry__.build()); this package has no CPU fallback" % LIB_PATH
