@@ -13,8 +13,8 @@ generator, seed in the JSON) and are resident in HBM before the timed region sta
 
 N>1: the global buffer (N x per-GPU size) is cut into contiguous chunks on word boundaries,
 rank r owns chunk r (cute_nucleotides_amd/sharding.py); there is no data-path collective --
-the process group is only used for the barrier and the max-over-ranks of the timing.  Weak
-scaling: per-GPU work is fixed.
+the process group (gloo over loopback by default, RCCL with CNT_BENCH_BACKEND=nccl) is only used
+for the barrier and the max-over-ranks of the timing.  Weak scaling: per-GPU work is fixed.
 
 Rank 0 prints ONE JSON line.  `value` counts every nucleotide converted per second over all
 ranks (N encoded + N decoded per step and rank), inputs already in HBM.  `roofline` is for
@@ -171,7 +171,10 @@ def main():
     # exercised on a 1-GPU box (RCCL refuses two ranks on one device).
     if os.environ.get("CNT_BENCH_SHARE_GPU") == "1":
         local_rank = 0
-    backend = os.environ.get("CNT_BENCH_BACKEND", "nccl")
+    # The process group carries no data: it is the barrier + a MAX/MIN of two scalars.  gloo over
+    # loopback is the default because it needs no GPU IPC and has been exercised with 2 ranks on the
+    # GPU box (tests/test_gpu_bench.py); CNT_BENCH_BACKEND=nccl runs the same control plane over RCCL.
+    backend = os.environ.get("CNT_BENCH_BACKEND", "gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
@@ -183,6 +186,7 @@ def main():
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group(backend=backend)
 
     import cute_nucleotides_amd as cn
@@ -274,7 +278,8 @@ def main():
                 "workload": "n_to_bits encode + bits_to_n decode of a device-resident uniform random ACGT buffer, "
                             "%.3g GiB (2^%d nt) per GPU" % (n_per / 2**30, args.log2_nt),
                 "nt_per_gpu": n_per, "nt_per_step": nt_per_step, "seed": hex(args.seed),
-                "sharding": "contiguous chunks on word boundaries, no collective" if world > 1 else "single GPU",
+                "sharding": ("contiguous chunks on word boundaries, no data-path collective; control plane: " + backend)
+                if world > 1 else "single GPU",
                 "encode_kernel": dict(devutil.variants("encode"))[devutil.get_tuning("encode")],
                 "decode_kernel": dict(devutil.variants("decode"))[devutil.get_tuning("decode")],
             },

@@ -40,7 +40,7 @@ def test_two_rank_launch_path_shares_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, CNT_BENCH_SHARE_GPU="1", CNT_BENCH_BACKEND="gloo")
+    env = dict(os.environ, CNT_BENCH_SHARE_GPU="1")  # default control-plane backend (gloo)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--log2-nt", "28", "--cpu-seconds", "0"]
