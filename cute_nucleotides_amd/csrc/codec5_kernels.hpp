@@ -157,7 +157,7 @@ static_assert(kWaveBytes5 % 16 == 0, "a round must be whole 16-B vectors");
 // reads the 8 dwords that cover the 27 bytes of word j*64+l, funnel-shifts them into place,
 // maps 4 bytes at a time to codes with v_perm_b32, and stores one u64 (8 B per lane,
 // 512 B per wave-instruction).
-template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT>
+template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
 __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                                uint64_t n_wave_tiles) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
@@ -165,7 +165,8 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
     // access whose descriptor depends on it in a waterfall loop (v_readfirstlane / s_and_saveexec)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint64_t t = blockIdx.x * (uint64_t)WAVES + wave;
+    // C > 1 (single-wave workgroups only): XCD-pair tile map, see tile_of_block
+    const uint64_t t = C > 1 ? tile_of_block<C>(blockIdx.x, n_wave_tiles) : blockIdx.x * (uint64_t)WAVES + wave;
     if (t >= n_wave_tiles) return;  // wave-uniform
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, TILE_BYTES);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 // dwords to the wave's LDS slab (every slab dword is written by exactly one lane -- no byte
 // stores; rounds are independent because 1728 B is dword aligned).  The tile then leaves
 // with WPL*108 coalesced 16-B stores.
-template <int WAVES, int WPL, int LAUX, int SAUX>
+template <int WAVES, int WPL, int LAUX, int SAUX, int C = 1>
 __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                                uint64_t n_wave_tiles) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
     // access whose descriptor depends on it in a waterfall loop (v_readfirstlane / s_and_saveexec)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint64_t t = blockIdx.x * (uint64_t)WAVES + wave;
+    // C > 1 (single-wave workgroups only): XCD-pair tile map, see tile_of_block
+    const uint64_t t = C > 1 ? tile_of_block<C>(blockIdx.x, n_wave_tiles) : blockIdx.x * (uint64_t)WAVES + wave;
     if (t >= n_wave_tiles) return;  // wave-uniform
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * (TILE_WORDS * 8), TILE_WORDS * 8);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_BYTES, TILE_BYTES);

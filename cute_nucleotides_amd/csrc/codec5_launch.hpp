@@ -22,11 +22,13 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},   // 6: as 0 without the residency cap
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 7
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 8
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=nt st=sc1, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 9
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=nt st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 10
 };
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 0: default
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 0: default
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64, 0},   // 1
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 2
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 3
@@ -35,6 +37,8 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},   // 6: as 0 without the residency cap
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 7
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 8
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 9: as 0 without the XCD pairing
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=nt st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 10
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -61,6 +65,8 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
             case 4: CNT_ENC2(1, 1, kNT, kSC1); break;
             case 5: CNT_ENC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: CNT_ENC2(1, 2, kNT, kSC1); break;
+            case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             default: return 1;
         }
 #undef CNT_ENC2
@@ -83,13 +89,15 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
 #define CNT_DEC2(W, P, L, S) \
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
-            case 0: CNT_DEC2(1, 2, 0, kAll); break;
+            case 0: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
             case 2: CNT_DEC2(2, 2, 0, kAll); break;
             case 3: CNT_DEC2(4, 2, 0, kAll); break;
             case 4: CNT_DEC2(1, 1, 0, kAll); break;
             case 5: CNT_DEC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
+            case 9: CNT_DEC2(1, 2, 0, kAll); break;
+            case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             default: return 1;
         }
 #undef CNT_DEC2
