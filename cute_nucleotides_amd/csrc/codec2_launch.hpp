@@ -24,7 +24,7 @@ inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (163840u / cap) / 256u 
 
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
-    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 0: default
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 0: default
     {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16, 256, 0},              // 1
     {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16, 512, 0},          // 2
     {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16, 256, 0},               // 3: the first shape tried
@@ -33,8 +33,11 @@ constexpr VariantDesc kEncodeVariants[] = {
     {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16, 128, 0},              // 6
     {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16, 64, 0},      // 7
     {"stream B=256 U=4 plain", 256 * 4 * 16, 256, 0},                     // 8: no cache-policy bits at all
-    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1 (no residency cap)", 64 * 2 * 16, 64, 0},  // 9: as 0, uncapped
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1 (no residency cap)", 64 * 2 * 16, 64, 0},  // 9: as 11, uncapped
     {"stream B=128 U=2 ld=nt st=sc1, 10 wg/CU", 128 * 2 * 16, 128, 10},   // 10
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc1, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 11: as 0 with write-through-only stores
+    {"stream B=64 U=2 xcd-pairs ld=sc0|nt st=sc1, 22 wg/CU", 64 * 2 * 16, 64, 22},  // 12
+    {"stream B=64 U=2 xcd-pairs ld=sc0|nt st=sc0|sc1|nt, 22 wg/CU", 64 * 2 * 16, 64, 22},  // 13
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -64,7 +67,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
 #define CNT_ENC_STREAM(B, U, C, L, S) \
     hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, n_tiles)
     switch (variant) {
-        case 0: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
+        case 0: CNT_ENC_STREAM(64, 2, 2, kNT, kSC0 | kSC1 | kNT); break;
         case 1: CNT_ENC_STREAM(256, 1, 1, kNT, kSC1); break;
         case 2: CNT_ENC_STREAM(512, 1, 1, kSC0 | kNT, kSC1); break;
         case 3: CNT_ENC_STREAM(256, 4, 1, kNT, kNT); break;
@@ -75,6 +78,9 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
         case 8: CNT_ENC_STREAM(256, 4, 1, 0, 0); break;
         case 9: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
         case 10: CNT_ENC_STREAM(128, 2, 1, kNT, kSC1); break;
+        case 11: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
+        case 12: CNT_ENC_STREAM(64, 2, 2, kSC0 | kNT, kSC1); break;
+        case 13: CNT_ENC_STREAM(64, 2, 2, kSC0 | kNT, kSC0 | kSC1 | kNT); break;
         default: return 1;
     }
     }
