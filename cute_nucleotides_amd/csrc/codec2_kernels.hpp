@@ -17,10 +17,13 @@
 //     then a compact, advancing address window;
 //   * 16 B per lane on the wide side, the narrow side simply 4 B per lane --
 //     staging the narrow side through LDS to widen it to 16 B bought nothing;
-//   * cache policy matters: streaming (nt) loads + write-through (sc1) stores for
-//     encode, plain loads + sc0|sc1|nt stores for decode;
+//   * cache policy matters: streaming (nt) loads for encode, plain loads for decode,
+//     write-through non-temporal (sc0|sc1|nt) stores for both (for encode sc1 alone
+//     is as fast, but leaves the packed buffer in a state that slows the decode that
+//     follows by 1.3 %);
 //   * letting each XCD (block b runs on XCD b%8) own 4 KiB-contiguous pieces of
-//     the input is worth ~1 %.
+//     the wide side is worth 1-2 %;
+//   * capping residency at ~24 waves per CU (dummy LDS) is worth another 2-3 %.
 // Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
 // per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)
 // and exposes the sc0 / nt / sc1 bits that plain C++ loads and stores cannot.

@@ -101,6 +101,10 @@ constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=256 U=4 plain", 256 * 4 * 16, 256, 0},                         // 8: no cache-policy bits at all
     {"stream B=128 U=2 ld=plain st=sc0|sc1|nt (no residency cap)", 128 * 2 * 16, 128, 0},  // 9: as 10, uncapped
     {"stream B=128 U=2 ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 10: as 0 without the XCD pairing
+    {"stream B=128 U=2 xcd-pairs ld=nt st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 11
+    {"stream B=128 U=2 xcd-pairs ld=sc0|nt st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 12
+    {"stream B=128 U=2 xcd-pairs ld=plain st=sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 13
+    {"stream B=128 U=2 xcd-pairs ld=sc1 st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 14
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -131,6 +135,10 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 8: CNT_DEC_STREAM(256, 4, 1, 0, 0); break;
         case 9: CNT_DEC_STREAM(128, 2, 1, 0, kAll); break;
         case 10: CNT_DEC_STREAM(128, 2, 1, 0, kAll); break;
+        case 11: CNT_DEC_STREAM(128, 2, 2, kNT, kAll); break;
+        case 12: CNT_DEC_STREAM(128, 2, 2, kSC0 | kNT, kAll); break;
+        case 13: CNT_DEC_STREAM(128, 2, 2, 0, kSC1 | kNT); break;
+        case 14: CNT_DEC_STREAM(128, 2, 2, kSC1, kAll); break;
         default: return 1;
     }
     }
