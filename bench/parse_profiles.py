@@ -51,12 +51,13 @@ def main():
     w_cal = n / (write[k_write][0] * 1024.0)
     enc, dec = pick(fetch, "n_to_bits_"), pick(fetch, "bits_to_n_")
 
-    def traffic(name):
+    def traffic(name, algorithmic=None):
+        algorithmic = 1.25 * n if algorithmic is None else algorithmic
         rd = fetch[name][0] * 1024.0 * f_cal
         wr = write[name][0] * 1024.0 * w_cal
         return {"kernel": name, "launches": fetch[name][1], "FETCH_SIZE_KiB_mean": fetch[name][0],
                 "WRITE_SIZE_KiB_mean": write[name][0], "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
-                "hbm_bytes": int(rd + wr), "algorithmic_bytes": int(1.25 * n), "ratio_to_algorithmic": round((rd + wr) / (1.25 * n), 4)}
+                "hbm_bytes": int(rd + wr), "algorithmic_bytes": int(algorithmic), "ratio_to_algorithmic": round((rd + wr) / algorithmic, 4)}
 
     summary = {
         "tag": tag, "nt": n,
@@ -65,8 +66,15 @@ def main():
                         "probe_write": {"kernel": k_write, "true_bytes": n, "WRITE_SIZE_KiB_mean": write[k_write][0]},
                         "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); KiB units; gfx950 FETCH_SIZE reports 1/2 of wide reads"},
         "encode": traffic(enc), "decode": traffic(dec),
-        "copy_probe": traffic(pick(fetch, "k_copy<")),
+        "copy_probe": traffic(pick(fetch, "k_copy<"), 2.0 * n),
     }
+    n5 = 27 * (1 << 28)
+    for key, needle, alg in (("encode_5letter", "n_to_bits2_wave", n5 * (1 + 8 / 27)), ("decode_5letter", "bits_to_n2_wave", n5 * (1 + 8 / 27)),
+                             ("hamming", "hamming_tiles", 0.5 * n), ("complement", "complement_tiles", 0.5 * n),
+                             ("validate", "validate_tiles", 1.0 * n)):
+        hits = [k for k in fetch if needle in k]
+        if len(hits) == 1:
+            summary[key] = traffic(hits[0], alg)
     json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
     json.dump({"source": "profiles/%s_pmc_summary.json" % tag, "nt": n,
                "encode_bytes_per_launch": summary["encode"]["hbm_bytes"],

@@ -37,4 +37,23 @@ for _ in range(a.reps):
     cn.bits_to_n_dev(d_packed, n, out=d_out)
 torch.cuda.synchronize()
 assert devutil.count_mismatch(d_in, d_out) == 0
+# secondary kernels: 5-letter codec on a 27*2^28-nt prefix of the same buffers, packed-domain ops
+from cute_nucleotides_amd import packed_ops as po  # noqa: E402
+
+n5 = 27 * (1 << 28)
+if n5 <= n:
+    devutil.fill_random_acgtn(d_in[:n5], 7)
+    for _ in range(a.reps):
+        cn.n_to_bits2_dev(d_in[:n5], out=d_packed[: n5 // 27])
+        cn.bits_to_n2_dev(d_packed[: n5 // 27], n5, out=d_out[:n5])
+    torch.cuda.synchronize()
+    assert devutil.count_mismatch(d_in[:n5], d_out[:n5]) == 0
+devutil.fill_random_acgt(d_in, 0x5EED)
+cn.n_to_bits_dev(d_in, out=d_packed)
+other = torch.empty_like(d_packed)
+for _ in range(a.reps):
+    po.complement_dev(d_packed, n, out=other)
+    po.hamming_dev(d_packed, other, n)
+    po.validate_dev(d_in)
+torch.cuda.synchronize()
 print("pmc workload ok: n = 2^%d, reps = %d" % (a.log2_nt, a.reps))
