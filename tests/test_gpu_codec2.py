@@ -387,3 +387,26 @@ def test_host_tier_is_thread_safe_and_survives_shutdown(cn, oracle):
     # the calling thread can shut down and keep going
     assert _lib.lib().cnt_shutdown() == 0
     assert np.array_equal(cn.n_to_bits_hip(inputs[0]), wants[0])
+
+
+def test_large_ragged_sizes_64bit_indexing(cn, oracle, torch_cuda):
+    """> 2^32 nt with a ragged tail: the whole-tile kernels, the tail kernel's 64-bit word offsets and
+    the zero padding of the last word, checked at the very end of the buffer and by round trip."""
+    from cute_nucleotides_amd import devutil
+
+    torch = torch_cuda
+    n_len = (1 << 33) + 3 * 16384 + 2048 + 77
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d, 77)
+    packed = cn.n_to_bits_dev(d)
+    back = cn.bits_to_n_dev(packed, n_len)
+    assert devutil.count_mismatch(d, back) == 0
+    tail_nt = 3 * 16384 + 2048 + 77  # starts on a 32-aligned position: 2^33 % 32 == 0
+    host_tail = oracle.fill_random_acgt(tail_nt, 77, first_nt=1 << 33)
+    want = oracle.n_to_bits_lut(host_tail)
+    got = packed[(1 << 33) // 32 :].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    assert int(got[-1]) >> (2 * (n_len & 31)) == 0
+    # strict mode takes the same path with the validity filter
+    strict = cn.n_to_bits_dev(d, strict_lut=True)
+    assert devutil.count_mismatch(strict, packed) == 0

@@ -125,3 +125,20 @@ def test_every_variant(cn, oracle, key):
                     assert np.array_equal(got, oracle.bits_to_n2_lut(want, length)), (name, length)
     finally:
         devutil.set_tuning(key, old)
+
+
+def test_large_ragged_size_64bit_indexing(cn, oracle):
+    import torch
+
+    from cute_nucleotides_amd import devutil
+
+    n_len = 27 * ((1 << 28) + 12345) + 19  # ~7.2 Gi nt, > 2^32, ragged
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgtn(d, 31)
+    packed = cn.n_to_bits2_dev(d)
+    back = cn.bits_to_n2_dev(packed, n_len)
+    assert devutil.count_mismatch(d, back) == 0
+    tail_words = 5000
+    first_word = packed.numel() - tail_words
+    host = oracle.fill_random_acgtn(n_len - 27 * first_word, 31, first_nt=27 * first_word)
+    assert np.array_equal(packed[first_word:].cpu().numpy().view(np.uint64), oracle.n_to_bits2_lut(host))
