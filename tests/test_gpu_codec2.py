@@ -3,7 +3,6 @@ oracle on the same seeded inputs, the reference's known-answer vectors, every ke
 every edge case the reference tests or leaves undefined, and -- at BASELINE.json's full
 sizes -- size-independent properties (round trip, checksum of checksums).  Bit-exact: this
 is integer/byte work."""
-import ctypes
 
 import numpy as np
 import pytest
