@@ -65,7 +65,8 @@ def cpu_baseline(seconds):
     if not orc.port_cpu_ok():
         return {"value": None, "unit": "Gnt/s", "cores": 0, "kind": "port", "sample": "host CPU lacks AVX2/BMI2"}
     L = orc.lib()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = len(cpus)
     per_thread = 16 << 20  # 16 Mi nt per thread: past any per-core share of L2/L3
     n_len = max(1 << 28, cores * per_thread)
     n = np.empty(n_len, dtype=np.uint8)
@@ -84,6 +85,10 @@ def cpu_baseline(seconds):
         deadline = [0.0]
 
         def body(k):
+            try:  # pin: first touch (the fill pass) and every later pass of span k stay on one CPU / NUMA node
+                os.sched_setaffinity(0, {cpus[k % len(cpus)]})
+            except (AttributeError, OSError):
+                pass
             gate.wait()
             lo, hi = spans[k]
             while True:
@@ -143,7 +148,7 @@ def cpu_baseline(seconds):
     return {
         "reference_faithful_40k_GiBs": faithful,
         "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
-        "sample": "%d Mi random ACGT nt (%d threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
+        "sample": "%d Mi random ACGT nt (%d pinned threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
                   "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"
                   % (n_len >> 20, cores, seconds),
         "encode_gnts": round(encN, 3), "decode_gnts": round(decN, 3),
