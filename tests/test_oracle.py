@@ -146,3 +146,20 @@ def test_checksum_position_sensitive(oracle):
     w2 = w.copy()
     w2[[10, 11]] = w2[[11, 10]]
     assert oracle.checksum_words(w2) != c
+
+
+def test_oracle_selftest_under_asan_ubsan():
+    """The C restatements and the SIMD ports on exactly-sized heap buffers under
+    -fsanitize=address,undefined: no over-read / over-write, no UB (the reference has both)."""
+    import os
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-C", here, "asan"], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr + r.stdout) and "cannot find" in (r.stderr + r.stdout):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "oracle selftest ok" in r.stdout
