@@ -241,6 +241,12 @@ def main():
     elapsed = float(t.item())
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     dec_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    # slowest rank's per-kernel averages (for the aggregate encode / decode rates); rank 0's own
+    # times stay in `roofline*`, which describe one GPU
+    km = torch.tensor([enc_ms, dec_ms], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+    enc_ms_max, dec_ms_max = float(km[0].item()), float(km[1].item())
 
     verified = None
     if not args.no_verify:
@@ -290,6 +296,9 @@ def main():
             },
             "encode_gnts_per_gpu": round(n_len / (enc_ms * 1e-3) / 1e9, 3),
             "decode_gnts_per_gpu": round(n_len / (dec_ms * 1e-3) / 1e9, 3),
+            "encode_gnts_all_gpus": round(n_global / (enc_ms_max * 1e-3) / 1e9, 3),
+            "decode_gnts_all_gpus": round(n_global / (dec_ms_max * 1e-3) / 1e9, 3),
+            "hbm_read_roofline_frac_encode_per_gpu": round(n_per / (enc_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
                 "kernel": "n_to_bits (encode)", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4),
