@@ -178,6 +178,43 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
         __builtin_amdgcn_raw_buffer_store_b32(enc16<STRICT>(v[u]), rout, (u * BLOCK + tid) * 4, 0, SAUX);
 }
 
+// WINDOW: variant 0's shape (one wave, 2 KiB in, 512 B out) for an input that starts at ANY
+// byte address.  The wave loads the 128-B-aligned window that covers its tile -- `in` is the
+// caller's pointer rounded down to a line, `phase` (1..127) the bytes dropped -- so every load
+// is a whole-line access exactly as in the aligned kernel; each lane packs the ALIGNED 16 bytes
+// it loaded, and the byte phase is then applied to the packed codes, which are 4x smaller:
+// output dword c = bits [2*(phase%16) ..) of code dword c + phase/16 and its successor, fetched
+// from the wave's LDS slab and funnel-shifted (v_alignbit_b32).  The slab is the dynamic-LDS
+// allocation that already caps residency (>= 768 B; one wave per workgroup, so it is private).
+// A tile reads up to 127 B before and 144 B behind itself; the launcher keeps both inside the
+// caller's buffer.  (The OUTPUT side cannot be treated this way -- a store stream that is not
+// 64-B aligned costs ~30 %, profiles/r01_align_lab*.json -- so the launcher peels head words until
+// the stores are line-aligned and hands the resulting input phase here.)
+template <int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          uint64_t n_tiles, uint32_t phase) {
+    constexpr uint32_t TILE_IN = kWave * 2 * 16, TILE_OUT = TILE_IN / 4, SLACK = 144;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + SLACK);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q = phase >> 4, sh = (phase & 15) << 1;
+    // lanes 0..q fetch the q+1 vectors behind the tile; the others aim past the descriptor's range,
+    // which returns 0 without touching memory
+    const uint32_t off2 = lane <= q ? (2 * kWave + lane) * 16 : 0xFFFFFF00u;
+    const u32x4 v0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, LAUX));
+    const u32x4 v1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (kWave + lane) * 16, 0, LAUX));
+    const u32x4 v2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off2, 0, LAUX));
+    residency_pad[lane] = enc16<STRICT>(v0);
+    residency_pad[kWave + lane] = enc16<STRICT>(v1);
+    residency_pad[2 * kWave + lane] = enc16<STRICT>(v2);
+    wave_lds_fence();
+    const uint32_t o0 = __builtin_amdgcn_alignbit(residency_pad[lane + q + 1], residency_pad[lane + q], sh);
+    const uint32_t o1 = __builtin_amdgcn_alignbit(residency_pad[kWave + lane + q + 1], residency_pad[kWave + lane + q], sh);
+    __builtin_amdgcn_raw_buffer_store_b32(o0, rout, lane * 4, 0, SAUX);
+    __builtin_amdgcn_raw_buffer_store_b32(o1, rout, (kWave + lane) * 4, 0, SAUX);
+}
+
 // LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,
 // packs to U dwords per lane, parks them in its private LDS slab in output order
 // (ds_write_b32, conflict-free), reads back 16 B per lane (ds_read_b128) and
@@ -254,6 +291,33 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_stream(const uint8_t* __restr
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
 }
 
+// SHIFTED: output tile-aligned, the packed stream entered at any even bit position.  `in` is
+// the dword that holds the tile sequence's first nucleotide, `sh` = 2 * (its index in that
+// dword's 16): a lane funnel-shifts two adjacent dwords (v_alignbit_b32) into its 32 bits.  The
+// second dword holds bits of the lane's own last nucleotides (sh > 0), so nothing past the
+// caller's `len` is read.  Used after the launcher has peeled head nucleotides to line-align
+// the stores.
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void bits_to_n_shifted(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           uint64_t n_tiles, uint32_t sh) {
+    constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + 4);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t tid = threadIdx.x;
+    uint32_t x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (u * BLOCK + tid) * 4, 0, LAUX);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (u * BLOCK + tid) * 4 + 4, 0, LAUX);
+        x[u] = __builtin_amdgcn_alignbit(hi, lo, sh);
+    }
+    touch_residency_pad(n_tiles, x[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
+}
+
 // LDS (measured alternative): each wave loads U/4 x 1 KiB of packed words as
 // 16-B vectors, parks them in its LDS slab (ds_write_b128), re-reads dword
 // (u*64+lane) (ds_read_b32, conflict-free) and stores U coalesced 16-B vectors.
@@ -298,6 +362,16 @@ __global__ __launch_bounds__(kBlock) void bits_to_n_generic(const uint64_t* __re
             for (int j = 0; j < 4; ++j)
                 if (k + j < m) out[i0 + k + j] = (uint8_t)(d >> (8 * j));
         }
+    }
+}
+
+// Nucleotide range [lo, hi) of a decode, one thread per nucleotide: the head a launcher peels
+// to line-align the stores of the tile kernels, and the ragged end behind them.
+__global__ __launch_bounds__(kBlock) void bits_to_n_range(const uint64_t* __restrict__ bits, uint8_t* __restrict__ out,
+                                                          uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo + blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t code = (uint32_t)(bits[i >> 5] >> ((i & 31) << 1)) & 3u;
+        out[i] = (uint8_t)(0x47544341u >> (code << 3));  // "ACTG"[code], n_to_bits.rs:23-30
     }
 }
 

@@ -50,7 +50,7 @@ inline unsigned grid_of(uint64_t n_tiles) { return (unsigned)(n_tiles > 0x7FFFFF
 inline uint64_t max_tiles_per_launch(int block) { return ((0x7FFFFFFFull / (uint64_t)block) / 64) * 64; }
 
 // Launches the whole-tile part of an encode; *done_nt = nucleotides covered (a multiple of
-// the variant's tile).  Pointers must be 16-B aligned.  Returns 0 / 1 (bad variant).
+// the variant's tile).  d_n must be 16-B aligned, d_out 4-B (16-B for the lds variant).  Returns 0 / 1 (bad variant).
 template <bool STRICT>
 int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_nt) {
     if (variant < 0 || variant >= kNumEncodeVariants) return 1;
@@ -86,6 +86,21 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
     }
 #undef CNT_ENC_STREAM
     return 0;
+}
+
+// The any-alignment companion of variant 0 (same shape, cache policy and residency cap):
+// `base` = input pointer rounded down to 128 B, `phase` = the 1..127 bytes dropped.
+constexpr uint32_t kWindowEncodeTile = 64 * 2 * 16;
+constexpr uint32_t kWindowEncodeSlack = 144;  // bytes a tile may read behind its end
+template <bool STRICT>
+void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(64);
+    const uint32_t lds = lds_for_cap(23);  // doubles as the kernel's 768-B exchange slab
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+        const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        hipLaunchKernelGGL((n_to_bits_window<2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+                           base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), n_tiles, phase);
+    }
 }
 
 // ---- decode -------------------------------------------------------------------------
@@ -144,6 +159,19 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     }
 #undef CNT_DEC_STREAM
     return 0;
+}
+
+// The any-alignment companion of decode variant 0: `in` = the dword holding the first
+// nucleotide, `sh` = 2 * (its index among that dword's 16).
+constexpr uint32_t kShiftedDecodeTile = 128 * 2 * 16;
+inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(128);
+    const uint32_t lds = lds_for_cap(13);
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+        const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        hipLaunchKernelGGL((bits_to_n_shifted<128, 2, 2, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(128), lds, s,
+                           in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, n_tiles, sh);
+    }
 }
 
 }  // namespace cnt

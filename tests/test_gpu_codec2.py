@@ -342,6 +342,77 @@ def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda):
         assert np.array_equal(got, want), c
 
 
+# ---- any-alignment plan: head peel + funnel-shifted loads (csrc/cute_nt.hip encode_dev/decode_dev) ----
+ALIGN_IN_OFFS = [0, 1, 2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 127]
+ALIGN_OUT_WORD_OFFS = [0, 1, 2, 3, 7, 8, 15]
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_encode_alignment_matrix(cn, oracle, torch_cuda, strict):
+    """Every input byte phase x output word phase, sizes on both sides of the peel/tile/guard
+    boundaries, guard values around the output: bit-exact and nothing written outside."""
+    torch = torch_cuda
+    if True:
+        sizes = [2048 * 3 + 144 + 5, 512 + 2048 + 143, 512 + 2048 + 144, 512 + 2048 + 145, 40000, 100003]
+        big = _rand_valid(max(sizes), 77) if not strict else np.random.default_rng(78).integers(0, 256, max(sizes), dtype=np.uint8)
+        ibuf = torch.zeros(big.size + 256, dtype=torch.uint8, device="cuda")
+        obuf = torch.empty(big.size // 32 + 64, dtype=torch.int64, device="cuda")
+        for n_len in sizes:
+            n = big[:n_len]
+            want = oracle.n_to_bits_lut(n)  # valid alphabet (fast mode) or any bytes under CNT_STRICT_LUT
+            words = (n_len + 31) // 32
+            for io in ALIGN_IN_OFFS:
+                view = ibuf[io : io + n_len]
+                view.copy_(torch.from_numpy(n))
+                for oo in ALIGN_OUT_WORD_OFFS:
+                    obuf.fill_(-1)
+                    out = obuf[8 + oo : 8 + oo + words]
+                    cn.n_to_bits_dev(view, out=out, strict_lut=strict)
+                    got = obuf.cpu().numpy()
+                    assert (got[: 8 + oo] == -1).all() and (got[8 + oo + words :] == -1).all(), (n_len, io, oo)
+                    assert np.array_equal(got[8 + oo : 8 + oo + words].view(np.uint64), want), (n_len, io, oo)
+
+
+def test_decode_alignment_matrix(cn, oracle, torch_cuda):
+    """Every output byte phase (mod 128) x packed-word phase, lengths around the boundaries."""
+    torch = torch_cuda
+    bits = np.random.default_rng(5).integers(0, 2**64, 4000, dtype=np.uint64)
+    dbuf = torch.zeros(bits.size + 16, dtype=torch.int64, device="cuda")
+    obuf = torch.empty(bits.size * 32 + 512, dtype=torch.uint8, device="cuda")
+    lens = [4096 + 127, 4096 + 128, 4096 + 129, 3 * 4096 + 77, 100003, bits.size * 32]
+    want_full = oracle.bits_to_n_lut(bits, bits.size * 32)
+    for wo in (0, 1, 3):
+        d = dbuf[wo : wo + bits.size]
+        d.copy_(torch.from_numpy(bits.view(np.int64)))
+        for oo in list(range(0, 36)) + [47, 48, 63, 64, 65, 96, 111, 127]:
+            for length in lens:
+                obuf.fill_(0x2A)
+                cn.bits_to_n_dev(d, length, out=obuf[128 + oo : 128 + oo + length])
+                got = obuf.cpu().numpy()
+                assert (got[: 128 + oo] == 0x2A).all() and (got[128 + oo + length :] == 0x2A).all(), (wo, oo, length)
+                assert np.array_equal(got[128 + oo : 128 + oo + length], want_full[:length]), (wo, oo, length)
+
+
+
+def test_decode_large_buffer_4k_head(cn, oracle, torch_cuda):
+    """>= 2^20 nt: the head is peeled up to a 4-KiB boundary of the output (range kernel), then the
+    funnel-shifting tiles, then a ragged end that does not start on a word."""
+    torch = torch_cuda
+    words = 40000
+    bits = np.random.default_rng(6).integers(0, 2**64, words, dtype=np.uint64)
+    d = torch.from_numpy(bits.view(np.int64)).cuda()
+    want = oracle.bits_to_n_lut(bits, words * 32)
+    obuf = torch.empty(words * 32 + 3 * 4096, dtype=torch.uint8, device="cuda")
+    base = (-obuf.data_ptr()) % 4096  # obuf[base] is 4-KiB aligned
+    for oo in (0, 1, 16, 100, 2048, 2049, 4095):
+        for length in (words * 32, words * 32 - 4097, (1 << 20) + 5):
+            obuf.fill_(0x2A)
+            cn.bits_to_n_dev(d, length, out=obuf[base + oo : base + oo + length])
+            got = obuf.cpu().numpy()
+            assert (got[: base + oo] == 0x2A).all() and (got[base + oo + length :] == 0x2A).all(), (oo, length)
+            assert np.array_equal(got[base + oo : base + oo + length], want[:length]), (oo, length)
+
+
 # ---- boundary behaviour of the C ABI -------------------------------------------------------
 def test_output_pointer_only_8_byte_aligned(cn, oracle, torch_cuda):
     """u64 outputs need 8-B alignment; 16-B is only needed for the fast path."""
