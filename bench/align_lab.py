@@ -33,14 +33,20 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--offsets", default="0,8,16,32,64,1,5,100")
     ap.add_argument("--packed-offsets", default="")
+    ap.add_argument("--five", action="store_true", help="the 5-letter codec instead of the 2-bit one")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "align_lab.json"))
     args = ap.parse_args()
     n = 1 << args.log2_nt
+    if args.five:
+        n = n // 3456 * 3456
+    per, bpn = (27, 1 + 8 / 27) if args.five else (32, 1.25)
+    enc = cn.n_to_bits2_dev if args.five else cn.n_to_bits_dev
+    dec = cn.bits_to_n2_dev if args.five else cn.bits_to_n_dev
     dev = torch.device("cuda", 0)
     pad = 16384
     b_in = torch.empty(n + pad, dtype=torch.uint8, device=dev)
     b_out = torch.empty(n + pad, dtype=torch.uint8, device=dev)
-    b_pk = torch.empty(n // 32 + pad // 8, dtype=torch.int64, device=dev)
+    b_pk = torch.empty(n // per + pad // 8, dtype=torch.int64, device=dev)
     offs = [int(x) for x in args.offsets.split(",")]
     poffs = [int(x) for x in args.packed_offsets.split(",")] if args.packed_offsets else None
     rows = []
@@ -50,19 +56,19 @@ def main():
                 continue
             d_in = b_in[a_off:a_off + n]
             d_out = b_out[a_off:a_off + n]
-            d_pk = b_pk[p_off // 8:p_off // 8 + n // 32]
-            devutil.fill_random_acgt(b_in[:n], 0x5EED)
+            d_pk = b_pk[p_off // 8:p_off // 8 + n // per]
+            (devutil.fill_random_acgtn if args.five else devutil.fill_random_acgt)(b_in[:n], 0x5EED)
             d_in.copy_(b_in[:n].clone())
-            cn.n_to_bits_dev(d_in, out=d_pk)
-            cn.bits_to_n_dev(d_pk, n, out=d_out)
+            enc(d_in, out=d_pk)
+            dec(d_pk, n, out=d_out)
             assert devutil.count_mismatch(d_in.contiguous(), d_out.contiguous()) == 0 if a_off % 16 == 0 else bool((d_in == d_out).all())
             te, td = [], []
             for _ in range(args.rounds):
-                te.append(timed(lambda: cn.n_to_bits_dev(d_in, out=d_pk), args.iters))
-                td.append(timed(lambda: cn.bits_to_n_dev(d_pk, n, out=d_out), args.iters))
+                te.append(timed(lambda: enc(d_in, out=d_pk), args.iters))
+                td.append(timed(lambda: dec(d_pk, n, out=d_out), args.iters))
             r = {"ascii_off": a_off, "packed_off": p_off,
-                 "encode_GBs": round(1.25 * n / statistics.median(te) / 1e6, 1),
-                 "decode_GBs": round(1.25 * n / statistics.median(td) / 1e6, 1)}
+                 "encode_GBs": round(bpn * n / statistics.median(te) / 1e6, 1),
+                 "decode_GBs": round(bpn * n / statistics.median(td) / 1e6, 1)}
             print(json.dumps(r), flush=True)
             rows.append(r)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

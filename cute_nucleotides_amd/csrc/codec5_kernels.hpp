@@ -153,6 +153,25 @@ constexpr int kWaveVecs5 = kWaveBytes5 / 16;    // 108
 constexpr int kWaveDwords5 = kWaveBytes5 / 4;   // 432
 static_assert(kWaveBytes5 % 16 == 0, "a round must be whole 16-B vectors");
 
+// The 27 bytes at byte position `byte0` of a wave's LDS slab -> one packed word: 8 dword reads
+// cover them, a funnel shift removes the byte phase, v_perm_b32 maps 4 bytes at a time to codes.
+// Reads dwords byte0/4 .. byte0/4 + 7 (the slabs are padded for the last lane).
+template <bool STRICT>
+__device__ __forceinline__ uint64_t word_from_slab(const uint32_t* my, uint32_t byte0) {
+    const uint32_t q = byte0 >> 2, s8 = (byte0 & 3u) * 8u;
+    uint32_t raw[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) raw[d] = my[q + d];
+    uint32_t c[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+        uint32_t x = (uint32_t)((((uint64_t)raw[d + 1] << 32) | raw[d]) >> s8);  // funnel shift right by the byte phase
+        if (d == 6) x &= 0x00FFFFFFu;                                             // bytes 24..26 only
+        c[d] = code5<STRICT>(x);
+    }
+    return pack27(c);
+}
+
 // Encode: WPL*108 coalesced 16-B loads into the wave's LDS slab; then, per round j, lane l
 // reads the 8 dwords that cover the 27 bytes of word j*64+l, funnel-shifts them into place,
 // maps 4 bytes at a time to codes with v_perm_b32, and stores one u64 (8 B per lane,
@@ -186,19 +205,44 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
     typedef unsigned int vu2 __attribute__((__vector_size__(8)));
 #pragma unroll
     for (int j = 0; j < WPL; ++j) {
-        const uint32_t byte0 = 27u * lane;  // + 1728*j, which is dword aligned: same phase every round
-        const uint32_t q = (byte0 >> 2) + kWaveDwords5 * j, s8 = (byte0 & 3u) * 8u;
-        uint32_t raw[8];
+        // byte 27*lane + 1728*j of the slab; 1728 is dword aligned: same phase every round
+        const uint64_t word = word_from_slab<STRICT>(my, 27u * lane + (uint32_t)kWaveBytes5 * j);
+        const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
+    }
+}
+
+// WINDOW: the default shape (one wave, 2 words per lane, 3456 B in, 1 KiB out) for an input at
+// ANY byte address -- the 5-letter counterpart of n_to_bits_window.  `in` is the caller's
+// pointer rounded down to 128 B and `phase` (1..127) the bytes dropped; the wave stages the
+// aligned window that covers its tile (216 + 8 vectors) in its slab, and since every lane
+// already picks its 27 bytes out of the slab at an arbitrary byte position, the phase is just an
+// offset into it.  Reads up to 127 B before and 128 B behind the tile (launcher's business).
+template <int LAUX, int SAUX, bool STRICT, int C>
+__global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        uint64_t n_wave_tiles, uint32_t phase) {
+    constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, WIN_VECS = kWaveVecs5 * WPL + 8;
+    __shared__ __attribute__((aligned(16))) uint32_t my[WIN_VECS * 4 + 4];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_wave_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, WIN_VECS * 16);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
+    constexpr int NLD = (WIN_VECS + 63) / 64;
+    u32x4 v[NLD];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) raw[d] = my[q + d];  // q + 7 <= 432*WPL + 3: inside the padded slab
-        uint32_t c[7];
+    for (int i = 0; i < NLD; ++i) {
+        v[i] = u32x4{0, 0, 0, 0};
+        if ((i + 1) * 64 <= WIN_VECS || lane < WIN_VECS - i * 64)
+            v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
+    }
 #pragma unroll
-        for (int d = 0; d < 7; ++d) {
-            uint32_t x = (uint32_t)((((uint64_t)raw[d + 1] << 32) | raw[d]) >> s8);  // funnel shift right by the byte phase
-            if (d == 6) x &= 0x00FFFFFFu;                                             // bytes 24..26 only
-            c[d] = code5<STRICT>(x);
-        }
-        const uint64_t word = pack27(c);
+    for (int i = 0; i < NLD; ++i)
+        if ((i + 1) * 64 <= WIN_VECS || lane < WIN_VECS - i * 64) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
+    wave_lds_fence();
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) {
+        const uint64_t word = word_from_slab<STRICT>(my, phase + 27u * lane + (uint32_t)kWaveBytes5 * j);  // <= 3556
         const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
         __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
     }

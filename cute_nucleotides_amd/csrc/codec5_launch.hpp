@@ -74,6 +74,21 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
     return 0;
 }
 
+// The any-alignment companion of encode2 variant 0: `base` = input pointer rounded down to 128 B,
+// `phase` = the 1..127 bytes dropped.  Same LDS footprint per workgroup as variant 0 (24 wg/CU).
+constexpr uint32_t kWindowEncode2Tile = 2 * kWaveBytes5;  // nt per tile (128 words)
+constexpr uint32_t kWindowEncode2Slack = 128;             // bytes a tile may read behind its end
+template <bool STRICT>
+void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
+    const uint32_t lds = lds_for_cap(24) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+        const uint64_t n = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        hipLaunchKernelGGL((n_to_bits2_window<kNT, kSC1, STRICT, 1>), dim3(grid_of(n)), dim3(64), lds, s,
+                           base + first * kWindowEncode2Tile, out + first * 1024, n, phase);
+    }
+}
+
 inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_words) {
     if (variant < 0 || variant >= kNumDecode2Variants) return 1;
     const uint64_t tile_nt = kDecode2Variants[variant].tile_nt, tile_words = tile_nt / 27;

@@ -325,6 +325,10 @@ int decode_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsign
     return CNT_OK;
 }
 
+// 5-letter codec, same alignment plan.  Encode: <= 7 head words make the stores 64-B aligned, the
+// input phase goes to n_to_bits2_window.  Decode: the stores are the wide side and 27 is a unit
+// mod 128, so a head of k = 19 * (-address mod 128) mod 128 words (27 * 19 = 1 mod 128) puts the
+// remaining output on a 128-B line for ANY pointer; the packed side just moves by k words.
 int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, hipStream_t s) {
     const size_t words = cnt_words2_for(n_len);
     if (out_words < words) return CNT_ECAP;
@@ -332,24 +336,44 @@ int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, un
     if (n_len == 0) return CNT_OK;
     if (!d_n || !d_out || !aligned(d_out, 8)) return CNT_EINVAL;
     const bool strict = (flags & CNT_STRICT_LUT) != 0;
-    uint64_t done_words = 0;
-    if (aligned(d_n, 16)) {
-        const int v = g_encode2_variant.load(std::memory_order_relaxed);
-        if (strict ? launch_encode2<true>(v, d_n, d_out, n_len, s, &done_words)
-                   : launch_encode2<false>(v, d_n, d_out, n_len, s, &done_words))
-            return CNT_EINVAL;
-        HIP_TRY(hipGetLastError());
-    }
-    if (done_words < words) {
-        const unsigned g = generic_grid(words - done_words);
+    const uint8_t* n = static_cast<const uint8_t*>(d_n);
+    uint64_t* out = static_cast<uint64_t*>(d_out);
+    auto generic = [&](uint64_t nt_end, uint64_t first_word, uint64_t end_word) {
+        if (first_word >= end_word) return;
+        const unsigned g = generic_grid(end_word - first_word);
         if (strict)
-            hipLaunchKernelGGL((n_to_bits2_generic<true>), dim3(g), dim3(kBlock), 0, s, static_cast<const uint8_t*>(d_n),
-                               (uint64_t)n_len, static_cast<uint64_t*>(d_out), done_words, (uint64_t)words);
+            hipLaunchKernelGGL((n_to_bits2_generic<true>), dim3(g), dim3(kBlock), 0, s, n, nt_end, out, first_word, end_word);
         else
-            hipLaunchKernelGGL((n_to_bits2_generic<false>), dim3(g), dim3(kBlock), 0, s, static_cast<const uint8_t*>(d_n),
-                               (uint64_t)n_len, static_cast<uint64_t*>(d_out), done_words, (uint64_t)words);
+            hipLaunchKernelGGL((n_to_bits2_generic<false>), dim3(g), dim3(kBlock), 0, s, n, nt_end, out, first_word, end_word);
+    };
+    uint64_t head_words = ((64 - (reinterpret_cast<uintptr_t>(d_out) & 63)) & 63) >> 3;
+    const uint32_t phase = (uint32_t)((reinterpret_cast<uintptr_t>(n) + 27 * head_words) & 127);
+    if (phase && head_words < 5) head_words += 8;  // 64 B of output; >= 127 B of input in front of the first window
+    const uint32_t phase2 = (uint32_t)((reinterpret_cast<uintptr_t>(n) + 27 * head_words) & 127);
+    uint64_t main_words = 0;
+    if (n_len > 27 * head_words) {
+        const uint64_t rem = n_len - 27 * head_words;
+        const uint8_t* p = n + 27 * head_words;
+        uint8_t* o = reinterpret_cast<uint8_t*>(out + head_words);
+        const int v = g_encode2_variant.load(std::memory_order_relaxed);
+        if (phase2 == 0 || ((phase2 & 15) == 0 && v != 0)) {
+            if (strict ? launch_encode2<true>(v, p, o, rem, s, &main_words) : launch_encode2<false>(v, p, o, rem, s, &main_words))
+                return CNT_EINVAL;
+        } else if (rem >= kWindowEncode2Tile + kWindowEncode2Slack) {
+            const uint64_t tiles = (rem - kWindowEncode2Slack) / kWindowEncode2Tile;
+            if (strict) launch_encode2_window<true>(p - phase2, phase2, o, tiles, s);
+            else launch_encode2_window<false>(p - phase2, phase2, o, tiles, s);
+            main_words = tiles * (kWindowEncode2Tile / 27);
+        }
         HIP_TRY(hipGetLastError());
     }
+    if (main_words == 0) {
+        generic(n_len, 0, words);
+    } else {
+        generic(27 * head_words, 0, head_words);
+        generic(n_len, head_words + main_words, words);
+    }
+    HIP_TRY(hipGetLastError());
     return CNT_OK;
 }
 
@@ -359,17 +383,28 @@ int decode2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsig
     if (len == 0) return CNT_OK;
     if (!d_bits || !d_out || !aligned(d_bits, 8)) return CNT_EINVAL;
     const size_t used_words = cnt_words2_for(len);
-    uint64_t done_words = 0;
-    if (aligned(d_out, 16)) {
-        if (launch_decode2(g_decode2_variant.load(std::memory_order_relaxed), d_bits, d_out, len, s, &done_words)) return CNT_EINVAL;
+    const uint64_t* bits = static_cast<const uint64_t*>(d_bits);
+    uint8_t* out = static_cast<uint8_t*>(d_out);
+    auto generic = [&](uint64_t nt_end, uint64_t first_word, uint64_t end_word) {
+        if (first_word >= end_word) return;
+        hipLaunchKernelGGL(bits_to_n2_generic, dim3(generic_grid(end_word - first_word)), dim3(kBlock), 0, s, bits, nt_end, out,
+                           first_word, end_word);
+    };
+    const uint64_t head_words = (19 * ((128 - (reinterpret_cast<uintptr_t>(d_out) & 127)) & 127)) & 127;
+    uint64_t main_words = 0;
+    if (len > 27 * head_words) {
+        if (launch_decode2(g_decode2_variant.load(std::memory_order_relaxed), bits + head_words, out + 27 * head_words,
+                           len - 27 * head_words, s, &main_words))
+            return CNT_EINVAL;
         HIP_TRY(hipGetLastError());
     }
-    if (done_words < used_words) {
-        hipLaunchKernelGGL(bits_to_n2_generic, dim3(generic_grid(used_words - done_words)), dim3(kBlock), 0, s,
-                           static_cast<const uint64_t*>(d_bits), (uint64_t)len, static_cast<uint8_t*>(d_out), done_words,
-                           (uint64_t)used_words);
-        HIP_TRY(hipGetLastError());
+    if (main_words == 0) {
+        generic(len, 0, used_words);
+    } else {
+        generic(27 * head_words, 0, head_words);
+        generic(len, head_words + main_words, used_words);
     }
+    HIP_TRY(hipGetLastError());
     return CNT_OK;
 }
 

@@ -101,10 +101,9 @@ int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_
 /* ---- device-pointer tier: what the roofline metric measures ------------------- */
 /* Pointers are device memory on the calling thread's current device.  `stream`
  * is a hipStream_t (NULL = the legacy default stream); the call only enqueues.
- * 2-bit codec: ASCII pointers may have ANY alignment, word pointers 8 bytes; all
- * combinations run within a few percent of the aligned speed (a short head is peeled
- * so the stores are line-aligned, the loads absorb the phase).  5-letter codec: full
- * speed needs the ASCII pointer 16-byte aligned, otherwise a slower generic kernel.
+ * ASCII pointers may have ANY alignment, word pointers 8 bytes; all combinations
+ * run within a few percent of the aligned speed (a short head is peeled so the
+ * stores are line-aligned, the loads absorb the phase), both codecs.
  * n_to_bits: reads n_len bytes, writes ceil(n_len/32) words (last one zero-padded).
  * bits_to_n: reads ceil(len/32) words, writes exactly len bytes. */
 int cnt_n_to_bits_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *stream);

@@ -58,6 +58,54 @@ def test_device_tier_aligned_unaligned_and_overrun(cn, oracle):
         cn.bits_to_n2_dev(dbits, want.size * 27 + 1)
 
 
+@pytest.mark.parametrize("strict", [False, True])
+def test_encode_alignment_matrix(cn, oracle, strict):
+    """Any input byte phase x output word phase (head peel + n_to_bits2_window), sizes around the
+    peel / tile / slack boundaries, guard words around the output."""
+    import torch
+
+    sizes = [3456 + 27 * 15 + 127, 3456 + 27 * 15 + 128 + 27, 3456 * 3 + 500, 40003, 100003]
+    if strict:
+        big = np.random.default_rng(31).integers(0, 256, max(sizes), dtype=np.uint8)
+    else:
+        big = ALPHA[np.random.default_rng(30).integers(0, ALPHA.size, max(sizes))]
+    ibuf = torch.zeros(big.size + 256, dtype=torch.uint8, device="cuda")
+    obuf = torch.empty(big.size // 27 + 64, dtype=torch.int64, device="cuda")
+    for n_len in sizes:
+        n = big[:n_len]
+        want = oracle.n_to_bits2_lut(n)
+        for io in [0, 1, 2, 3, 5, 8, 15, 16, 17, 27, 33, 64, 77, 100, 127]:
+            view = ibuf[io : io + n_len]
+            view.copy_(torch.from_numpy(n))
+            for oo in (0, 1, 2, 3, 5, 7):
+                obuf.fill_(-1)
+                cn.n_to_bits2_dev(view, out=obuf[8 + oo : 8 + oo + want.size], strict_lut=strict)
+                got = obuf.cpu().numpy()
+                assert (got[: 8 + oo] == -1).all() and (got[8 + oo + want.size :] == -1).all(), (n_len, io, oo)
+                assert np.array_equal(got[8 + oo : 8 + oo + want.size].view(np.uint64), want), (n_len, io, oo)
+
+
+def test_decode_alignment_matrix(cn, oracle):
+    """Every output phase mod 128 (the head is 19 * (-phase) mod 128 whole words) x packed-word phase."""
+    import torch
+
+    words = 1500
+    bits = np.random.default_rng(32).integers(0, 2**63, words, dtype=np.uint64)
+    want_full = oracle.bits_to_n2_lut(bits, words * 27)
+    dbuf = torch.zeros(words + 8, dtype=torch.int64, device="cuda")
+    obuf = torch.empty(words * 27 + 512, dtype=torch.uint8, device="cuda")
+    for wo in (0, 1):
+        d = dbuf[wo : wo + words]
+        d.copy_(torch.from_numpy(bits.view(np.int64)))
+        for oo in range(128):
+            for length in (words * 27, words * 27 - 3456 - 5, 3456 + 127 * 27 + 1, 3456 + 127 * 27 - 1):
+                obuf.fill_(0x2A)
+                cn.bits_to_n2_dev(d, length, out=obuf[128 + oo : 128 + oo + length])
+                got = obuf.cpu().numpy()
+                assert (got[: 128 + oo] == 0x2A).all() and (got[128 + oo + length :] == 0x2A).all(), (wo, oo, length)
+                assert np.array_equal(got[128 + oo : 128 + oo + length], want_full[:length]), (wo, oo, length)
+
+
 def test_arbitrary_words_and_bytes(cn, oracle):
     """Words no encoder produces (7-bit fields 125..127, bit 63 set) decode like the oracle
     defines; strict mode encodes non-alphabet bytes as 0 like BYTE_LUT (n_to_bits2.rs:8-23)."""
