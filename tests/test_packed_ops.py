@@ -100,6 +100,39 @@ def test_gpu_validate(oracle):
 
 
 @gpu
+def test_gpu_ops_pointer_phases(oracle):
+    """Word pointers at every 8-B phase of a 128-B line (equal and unequal phases of the two
+    streams), ASCII pointers at odd bytes: heads are peeled, results and guard words unchanged."""
+    import torch
+
+    from cute_nucleotides_amd import packed_ops as po
+
+    rng = np.random.default_rng(9)
+    words = 3 * 8192 + 40
+    a = rng.integers(0, 2**64, words + 40, dtype=np.uint64)
+    b = a ^ (rng.integers(0, 2**64, words + 40, dtype=np.uint64) & rng.integers(0, 2**64, words + 40, dtype=np.uint64))
+    da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    obuf = torch.empty(words + 64, dtype=torch.int64, device="cuda")
+    for pa in (0, 1, 2, 3, 7, 8, 15, 16, 17):
+        for pb in (pa, pa + 1, pa + 2, 0):
+            for n_len in (words * 32, words * 32 - 45, 64 * 32 + 3):
+                w = (n_len + 31) // 32
+                got = int(po.hamming_dev(da[pa : pa + w], db[pb : pb + w], n_len).item())
+                assert got == oracle.hamming(a[pa : pa + w], b[pb : pb + w], n_len), (pa, pb, n_len)
+                obuf.fill_(-1)
+                po.complement_dev(da[pa : pa + w], n_len, out=obuf[8 + pb : 8 + pb + w])
+                o = obuf.cpu().numpy()
+                assert (o[: 8 + pb] == -1).all() and (o[8 + pb + w :] == -1).all()
+                assert np.array_equal(o[8 + pb : 8 + pb + w].view(np.uint64), oracle.complement(a[pa : pa + w], n_len)), (pa, pb, n_len)
+    n = rng.integers(0, 256, 5 * 65536 + 300, dtype=np.uint8)
+    d = torch.from_numpy(n).cuda()
+    for off in (0, 1, 7, 16, 100, 127, 128, 129):
+        for n_len in (n.size - off, 65536 + 127, 65536 + 128, 200):
+            for allow in (False, True):
+                assert int(po.validate_dev(d[off : off + n_len], allow_n=allow).item()) == oracle.validate(n[off : off + n_len], allow_n=allow)
+
+
+@gpu
 def test_gpu_large_properties(oracle):
     """2^32 nt: rc(rc(x)) == x, complement is an involution, hamming(x, complement(x)) == len,
     hamming(x, x) == 0, and encode(valid ASCII) validates clean."""
