@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -507,6 +508,67 @@ int host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, si
     return rc;
 }
 
+// ---- sharded tier: one persistent worker thread per device ---------------------------------
+// A worker keeps its device binding and its thread-local context (streams, pinned staging, device
+// scratch) between calls; spawning threads per call would re-create 2 x 32 MiB of pinned memory per
+// device every time.  The pool is created on first use and deliberately never destroyed: its
+// threads sleep on a condition variable until the process exits, so no HIP call can run from a
+// static destructor after the runtime is gone.  cnt_shutdown() asks the workers to release their
+// contexts.  One sharded call runs at a time (callers queue on call_m_).
+class ShardPool {
+   public:
+    static ShardPool& get() {
+        static ShardPool* p = new ShardPool;  // leaked on purpose, see above
+        return *p;
+    }
+    // fn(k) runs on the worker bound to device k, k in [0, ndev); returns the first non-OK status
+    int run(int ndev, const std::function<int(int)>& fn) {
+        std::lock_guard<std::mutex> one_call(call_m_);
+        std::unique_lock<std::mutex> lk(m_);
+        while ((int)workers_.size() < ndev) {
+            const int k = (int)workers_.size();
+            workers_.push_back(new Worker);
+            std::thread([this, k] { loop(k); }).detach();
+        }
+        for (int k = 0; k < ndev; ++k) workers_[k]->job = &fn;
+        pending_ = ndev;
+        cv_work_.notify_all();
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        for (int k = 0; k < ndev; ++k)
+            if (workers_[k]->rc != CNT_OK) return workers_[k]->rc;
+        return CNT_OK;
+    }
+    int size() {
+        std::lock_guard<std::mutex> lk(m_);
+        return (int)workers_.size();
+    }
+
+   private:
+    struct Worker {
+        const std::function<int(int)>* job = nullptr;
+        int rc = CNT_OK;
+    };
+    void loop(int k) {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return workers_[k]->job != nullptr; });
+            const std::function<int(int)>* job = workers_[k]->job;
+            lk.unlock();
+            int rc = hip_rc(hipSetDevice(k));
+            if (rc == CNT_OK) rc = (*job)(k);
+            lk.lock();
+            workers_[k]->rc = rc;
+            workers_[k]->job = nullptr;
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::mutex call_m_, m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<Worker*> workers_;
+    int pending_ = 0;
+};
+std::atomic<bool> g_shard_pool_used{false};
+
 int resolve_ndev(int ndev, int* out) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -564,10 +626,20 @@ int cnt_get_device(int* device) {
     return hip_rc(hipGetDevice(device));
 }
 
-int cnt_shutdown(void) {
+static int release_thread_ctx() {
     t_ctx.pool.stop();
     for (auto& kv : t_ctx.per_device) kv.second.release();
     t_ctx.per_device.clear();
+    return CNT_OK;
+}
+
+int cnt_shutdown(void) {
+    release_thread_ctx();
+    if (g_shard_pool_used.load()) {  // the sharded tier's workers hold contexts of their own
+        ShardPool& pool = ShardPool::get();
+        const int n = pool.size();
+        if (n > 0) return pool.run(n, [](int) -> int { return release_thread_ctx(); });
+    }
     return CNT_OK;
 }
 
@@ -600,21 +672,12 @@ int cnt_n_to_bits_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t 
     const size_t gran = 16384;
     size_t per = (n_len + ndev - 1) / ndev;
     per = (per + gran - 1) / gran * gran;
-    std::vector<int> rcs(ndev, CNT_OK);
-    std::vector<std::thread> th;
-    for (int k = 0; k < ndev; ++k) {
+    g_shard_pool_used.store(true);
+    return ShardPool::get().run(ndev, [=](int k) -> int {
         const size_t lo = std::min(n_len, per * k), hi = std::min(n_len, per * (k + 1));
-        if (lo >= hi) continue;
-        th.emplace_back([=, &rcs] {
-            int rc = hip_rc(hipSetDevice(k));
-            if (rc == CNT_OK) rc = cnt_n_to_bits(n + lo, hi - lo, out + (lo >> 5), cnt_words_for(hi - lo));
-            rcs[k] = rc;
-        });
-    }
-    for (auto& t : th) t.join();
-    for (int rc : rcs)
-        if (rc != CNT_OK) return rc;
-    return CNT_OK;
+        if (lo >= hi) return CNT_OK;
+        return cnt_n_to_bits(n + lo, hi - lo, out + (lo >> 5), cnt_words_for(hi - lo));
+    });
 }
 
 int cnt_bits_to_n_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
@@ -625,21 +688,12 @@ int cnt_bits_to_n_sharded(const uint64_t* bits, size_t words, size_t len, uint8_
     const size_t gran = 16384;
     size_t per = (len + ndev - 1) / ndev;
     per = (per + gran - 1) / gran * gran;
-    std::vector<int> rcs(ndev, CNT_OK);
-    std::vector<std::thread> th;
-    for (int k = 0; k < ndev; ++k) {
+    g_shard_pool_used.store(true);
+    return ShardPool::get().run(ndev, [=](int k) -> int {
         const size_t lo = std::min(len, per * k), hi = std::min(len, per * (k + 1));
-        if (lo >= hi) continue;
-        th.emplace_back([=, &rcs] {
-            int rc = hip_rc(hipSetDevice(k));
-            if (rc == CNT_OK) rc = cnt_bits_to_n(bits + (lo >> 5), cnt_words_for(hi - lo), hi - lo, out + lo);
-            rcs[k] = rc;
-        });
-    }
-    for (auto& t : th) t.join();
-    for (int rc : rcs)
-        if (rc != CNT_OK) return rc;
-    return CNT_OK;
+        if (lo >= hi) return CNT_OK;
+        return cnt_bits_to_n(bits + (lo >> 5), cnt_words_for(hi - lo), hi - lo, out + lo);
+    });
 }
 
 // ---- device tier --------------------------------------------------------------------
