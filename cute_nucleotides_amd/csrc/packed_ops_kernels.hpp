@@ -140,8 +140,8 @@ __device__ __forceinline__ uint64_t reverse_codes64(uint64_t x) {
 // reverse complement: output word w holds nt 32w..32w+31 = complement of input nt len-1-32w-k.
 // One thread per output word; each reads a 64-bit window that straddles two input words.
 __global__ __launch_bounds__(kBlock) void reverse_complement_words(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                                   uint64_t len, uint64_t n_words) {
-    for (uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock) {
+                                                                   uint64_t len, uint64_t first_word, uint64_t n_words) {
+    for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock) {
         // input nts p_lo .. p_lo+31 with p_lo = len - 32 - 32w (may be negative for the last output word)
         const int64_t p_lo = (int64_t)len - 32 - (int64_t)(w << 5);
         uint64_t window;
@@ -158,6 +158,41 @@ __global__ __launch_bounds__(kBlock) void reverse_complement_words(const uint64_
         if (rem < 32) x &= (1ull << (2 * rem)) - 1;
         out[w] = x;
     }
+}
+
+// Tile form of the same: one workgroup = BLOCK*2 consecutive OUTPUT words, two per lane (one 16-B
+// store, 4 KiB per workgroup).  Output words w0+2i, w0+2i+1 are the bit windows at input nt
+// P - 64i and P - 64i - 32 with P = len - 32 - 32*w0, so the window phase (P & 31) and the word
+// J = P >> 5 are tile-uniform and lane i needs input words J-2i-1, J-2i (one 16-B load at an
+// 8-B-aligned address) and, when the phase is not 0, J-2i+1 (an 8-B load; with phase 0 the lane aims
+// outside the descriptor and nothing is fetched).  The tile reads the input backwards, but each
+// wave-instruction still covers one contiguous 1 KiB span.  Only whole tiles whose windows lie
+// entirely inside the input: the launcher leaves the last len % (64*BLOCK) nt to the word kernel.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void reverse_complement_tiles(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                                   uint64_t len, uint64_t n_tiles) {
+    constexpr uint32_t TILE_W = BLOCK * 2;
+    const uint64_t w0 = (uint64_t)blockIdx.x * TILE_W;
+    const uint64_t P = len - 32 - (w0 << 5);
+    const uint64_t J = P >> 5;
+    const uint32_t sh = 2u * ((uint32_t)P & 31u);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + (J + 1 - TILE_W) * 8, (TILE_W + 2) * 8);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + w0 * 8, TILE_W * 8);
+    const uint32_t i = threadIdx.x;
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (TILE_W - 2 - 2 * i) * 8, 0, kNT));
+    const vu2 e = __builtin_amdgcn_raw_buffer_load_b64(rin, sh ? (TILE_W - 2 * i) * 8 : 0xFFFFFFF0u, 0, kNT);
+    const uint64_t wm = ((uint64_t)q.y << 32) | q.x;   // input word j-1
+    const uint64_t wj = ((uint64_t)q.w << 32) | q.z;   // input word j
+    const uint64_t wp = ((uint64_t)e[1] << 32) | e[0];  // input word j+1 (0 when sh == 0)
+    uint64_t win0 = wj >> sh, win1 = wm >> sh;
+    if (sh) {
+        win0 |= wp << (64 - sh);
+        win1 |= wj << (64 - sh);
+    }
+    const uint64_t o0 = reverse_codes64(win0) ^ 0xAAAAAAAAAAAAAAAAull, o1 = reverse_codes64(win1) ^ 0xAAAAAAAAAAAAAAAAull;
+    const u32x4 o = {(uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)o1, (uint32_t)(o1 >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, i * 16, 0, kSC0 | kSC1 | kNT);
 }
 
 // validity: count bytes outside the alphabet.  SWAR: zero byte in (x & 0xDF) ^ expect  <=> valid letter.

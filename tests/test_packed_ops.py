@@ -124,6 +124,16 @@ def test_gpu_ops_pointer_phases(oracle):
                 o = obuf.cpu().numpy()
                 assert (o[: 8 + pb] == -1).all() and (o[8 + pb + w :] == -1).all()
                 assert np.array_equal(o[8 + pb : 8 + pb + w].view(np.uint64), oracle.complement(a[pa : pa + w], n_len)), (pa, pb, n_len)
+    # reverse complement: output phase x every window phase (len % 32) x tile-count boundaries
+    for po_ in (0, 1, 2, 5, 15, 16):
+        for pi_ in (0, 1):
+            for n_len in [512 * 32 * 2 + k for k in (0, 1, 5, 31, 32, 33)] + [512 * 32 + 16 * 32 - 1, 512 * 32 + 15 * 32 + 1, words * 32 - 7, 40 * 32]:
+                w = (n_len + 31) // 32
+                obuf.fill_(-1)
+                po.reverse_complement_dev(da[pi_ : pi_ + w], n_len, out=obuf[8 + po_ : 8 + po_ + w])
+                o = obuf.cpu().numpy()
+                assert (o[: 8 + po_] == -1).all() and (o[8 + po_ + w :] == -1).all()
+                assert np.array_equal(o[8 + po_ : 8 + po_ + w].view(np.uint64), oracle.reverse_complement(a[pi_ : pi_ + w], n_len)), (po_, pi_, n_len)
     n = rng.integers(0, 256, 5 * 65536 + 300, dtype=np.uint8)
     d = torch.from_numpy(n).cuda()
     for off in (0, 1, 7, 16, 100, 127, 128, 129):
