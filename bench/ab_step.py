@@ -20,28 +20,35 @@ ap.add_argument("--enc", default="0,9")
 ap.add_argument("--dec", default="0,9")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--five", action="store_true", help="the 5-letter codec (tuning keys encode2 / decode2)")
 a = ap.parse_args()
 n = 1 << a.log2_nt
+if a.five:
+    n = n // 3456 * 3456
+per, bpn = (27, 1 + 8 / 27) if a.five else (32, 1.25)
+K_ENC, K_DEC = ("encode2", "decode2") if a.five else ("encode", "decode")
+enc_fn = cn.n_to_bits2_dev if a.five else cn.n_to_bits_dev
+dec_fn = cn.bits_to_n2_dev if a.five else cn.bits_to_n_dev
 d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
-d_packed = torch.empty(n // 32, dtype=torch.int64, device="cuda")
+d_packed = torch.empty(n // per, dtype=torch.int64, device="cuda")
 d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
-devutil.fill_random_acgt(d_in, 0x5EED)
+(devutil.fill_random_acgtn if a.five else devutil.fill_random_acgt)(d_in, 0x5EED)
 encs = [int(x) for x in a.enc.split(",")]
 decs = [int(x) for x in a.dec.split(",")]
 pairs = [(e, d) for e in encs for d in decs]
 res = {p: {"enc": [], "dec": [], "step": []} for p in pairs}
-names_e, names_d = dict(devutil.variants("encode")), dict(devutil.variants("decode"))
+names_e, names_d = dict(devutil.variants(K_ENC)), dict(devutil.variants(K_DEC))
 for r in range(a.rounds + 1):
     for p in pairs:
-        devutil.set_tuning("encode", p[0])
-        devutil.set_tuning("decode", p[1])
+        devutil.set_tuning(K_ENC, p[0])
+        devutil.set_tuning(K_DEC, p[1])
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
         torch.cuda.synchronize()
         for k in range(a.steps):
             ev[k][0].record()
-            cn.n_to_bits_dev(d_in, out=d_packed)
+            enc_fn(d_in, out=d_packed)
             ev[k][1].record()
-            cn.bits_to_n_dev(d_packed, n, out=d_out)
+            dec_fn(d_packed, n, out=d_out)
             ev[k][2].record()
         torch.cuda.synchronize()
         if r == 0:
@@ -50,9 +57,9 @@ for r in range(a.rounds + 1):
         res[p]["enc"].append(sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps)
         res[p]["dec"].append(sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps)
         res[p]["step"].append(ev[0][0].elapsed_time(ev[-1][2]) / a.steps)
-devutil.set_tuning("encode", 0)
-devutil.set_tuning("decode", 0)
+devutil.set_tuning(K_ENC, 0)
+devutil.set_tuning(K_DEC, 0)
 for p in sorted(pairs, key=lambda p: statistics.median(res[p]["step"])):
     e, d, s = (statistics.median(res[p][k]) for k in ("enc", "dec", "step"))
     print("enc v%-2d dec v%-2d  step %.4f ms  enc %.4f ms = %6.1f GB/s  dec %.4f ms = %6.1f GB/s   | %s | %s" % (
-        p[0], p[1], s, e, 1.25 * n / e / 1e6, d, 1.25 * n / d / 1e6, names_e[p[0]], names_d[p[1]]))
+        p[0], p[1], s, e, bpn * n / e / 1e6, d, bpn * n / d / 1e6, names_e[p[0]], names_d[p[1]]))

@@ -45,27 +45,48 @@ __device__ __forceinline__ uint32_t code5_strict(uint32_t x) {
     return c & ~((nz >> 5) | (nz >> 6) | (nz >> 7));
 }
 
+// the two halves of code5_fast, for callers that can skip the second one for a whole wave when
+// no lane saw a byte >= 0x80 (always, on text)
+__device__ __forceinline__ uint32_t code5_table(uint32_t x) {
+    return __builtin_amdgcn_perm(0x03040202u, 0x01000000u, x & 0x07070707u);
+}
+__device__ __forceinline__ uint32_t code5_clear_high(uint32_t x, uint32_t c) {
+    const uint32_t hi = x & 0x80808080u;
+    return c & ~((hi >> 5) | (hi >> 6) | (hi >> 7));
+}
+
 template <bool STRICT>
 __device__ __forceinline__ uint32_t code5(uint32_t x) {
     if constexpr (STRICT) return code5_strict(x);
     else return code5_fast(x);
 }
 
-// 27 codes (one per byte, 7 dwords, bytes past the end = 0) -> one packed word
+// 27 codes (one per byte, 7 dwords, each 0..4) -> one packed word.  A triplet's value
+// a + 5b + 25c is a byte dot product, so v_dot4_u32_u8 does it in one instruction when the
+// triplet sits inside a dword and in two (chained through the accumulator) when it straddles:
+// 13 dot products for the 9 fields.  Byte 27 (top byte of c[6]) has weight 0 everywhere and may
+// hold anything.
 __device__ __forceinline__ uint64_t pack27(const uint32_t (&c)[7]) {
-    uint64_t acc = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = 3 * t + j;
-            const uint32_t code = (c[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            v += code * (j == 0 ? 1u : j == 1 ? 5u : 25u);
-        }
-        acc |= (uint64_t)v << (7 * t);
-    }
-    return acc;
+    constexpr uint32_t W012 = 0x00190501u;  // bytes 0,1,2 of the dword  x (1, 5, 25)
+    constexpr uint32_t W3 = 0x01000000u;    // byte 3 x 1 ...
+    constexpr uint32_t W01 = 0x00001905u;   // ... continued by bytes 0,1 of the next dword x (5, 25)
+    constexpr uint32_t W23 = 0x05010000u;   // bytes 2,3 x (1, 5) ...
+    constexpr uint32_t W0 = 0x00000019u;    // ... continued by byte 0 of the next dword x 25
+    constexpr uint32_t W123 = 0x19050100u;  // bytes 1,2,3 x (1, 5, 25)
+#define CNT_DOT(A, W, ACC) __builtin_amdgcn_udot4((A), (W), (ACC), false)
+    const uint32_t v0 = CNT_DOT(c[0], W012, 0u);
+    const uint32_t v1 = CNT_DOT(c[1], W01, CNT_DOT(c[0], W3, 0u));
+    const uint32_t v2 = CNT_DOT(c[2], W0, CNT_DOT(c[1], W23, 0u));
+    const uint32_t v3 = CNT_DOT(c[2], W123, 0u);
+    const uint32_t v4 = CNT_DOT(c[3], W012, 0u);
+    const uint32_t v5 = CNT_DOT(c[4], W01, CNT_DOT(c[3], W3, 0u));
+    const uint32_t v6 = CNT_DOT(c[5], W0, CNT_DOT(c[4], W23, 0u));
+    const uint32_t v7 = CNT_DOT(c[5], W123, 0u);
+    const uint32_t v8 = CNT_DOT(c[6], W012, 0u);
+#undef CNT_DOT
+    const uint32_t lo = v0 | (v1 << 7) | (v2 << 14) | (v3 << 21) | (v4 << 28);
+    const uint32_t hi = (v4 >> 4) | (v5 << 3) | (v6 << 10) | (v7 << 17) | (v8 << 24);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // one 7-bit value -> 3 code digits (a,b,c) as bytes 0..2 of a dword; c clamped
@@ -93,6 +114,58 @@ __device__ __forceinline__ uint32_t field7(uint32_t lo, uint32_t hi) {
 __device__ __forceinline__ uint32_t letters5(uint32_t codes /* 4 code bytes, each 0..4 */) {
     // v_perm_b32 as an 8-entry table: 0..3 -> "ACTG", 4 -> 'N'
     return __builtin_amdgcn_perm(0x4E4E4E4Eu /* 'N' x4 = entries 4..7 */, 0x47544341u, codes);
+}
+
+// ---- decode arithmetic on field PAIRS ------------------------------------------------------
+// Two 7-bit values in the 16-bit halves of a dword -> their digits with packed 16-bit math
+// (v_pk_mul_lo_u16 / v_pk_lshrrev_b16 / v_pk_mad_u16: 6 instructions for both).  c may come out
+// as 5 for the values 125..127 no encoder produces; the letter table maps 4..7 to 'N', which is
+// what the clamp in digits3 does.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+struct PairLetters {
+    uint32_t t;  // letters of (a_even, b_even, a_odd, b_odd)
+    uint32_t c;  // letters of (c_even, -, c_odd, -)
+};
+__device__ __forceinline__ void digits_pair(uint32_t x, uint32_t& ab, uint32_t& cc) {
+    const u16x2 v = __builtin_bit_cast(u16x2, x);
+    const u16x2 c = (v * (unsigned short)41) >> (unsigned short)10;  // v/25, v < 128
+    const u16x2 r = v - c * (unsigned short)25;
+    const u16x2 b = (r * (unsigned short)13) >> (unsigned short)6;   // r/5, r < 69
+    const u16x2 a = r - b * (unsigned short)5;
+    ab = __builtin_bit_cast(uint32_t, a) | (__builtin_bit_cast(uint32_t, b) << 8);  // bytes a_e, b_e, a_o, b_o
+    cc = __builtin_bit_cast(uint32_t, c);                                            // bytes c_e, 0, c_o, 0
+}
+__device__ __forceinline__ PairLetters letters_pair(uint32_t x) {
+    uint32_t ab, cc;
+    digits_pair(x, ab, cc);
+    return PairLetters{letters5(ab), letters5(cc)};
+}
+
+// One packed word (lo, hi) -> its 27 letters as 7 dwords (top byte of b[6] = 0).  v_perm_b32
+// with constant selectors weaves the pair results into string order: per pair the string bytes
+// are t0 t1 c0 t2 | t3 c2.
+__device__ __forceinline__ void decode27(uint32_t lo, uint32_t hi, uint32_t (&b)[7]) {
+    const uint32_t f4 = __builtin_amdgcn_alignbit(hi, lo, 28) & 0x7Fu;  // the field that straddles the dwords
+    const uint32_t x0 = __builtin_amdgcn_ubfe(lo, 0, 7) | (__builtin_amdgcn_ubfe(lo, 7, 7) << 16);
+    const uint32_t x1 = __builtin_amdgcn_ubfe(lo, 14, 7) | (__builtin_amdgcn_ubfe(lo, 21, 7) << 16);
+    const uint32_t x2 = f4 | (__builtin_amdgcn_ubfe(hi, 3, 7) << 16);
+    const uint32_t x3 = __builtin_amdgcn_ubfe(hi, 10, 7) | (__builtin_amdgcn_ubfe(hi, 17, 7) << 16);
+    const uint32_t x4 = __builtin_amdgcn_ubfe(hi, 24, 7);
+    const PairLetters p0 = letters_pair(x0), p1 = letters_pair(x1), p2 = letters_pair(x2), p3 = letters_pair(x3);
+    // perm(hi_src, lo_src, sel): selector bytes 0..3 pick from lo_src, 4..7 from hi_src, 0x0C gives 0
+    constexpr uint32_t kHead = 0x02040100u;  // t0 t1 c0 t2        (string bytes 0..3 of a pair)
+    constexpr uint32_t kRest = 0x0C0C0603u;  // t3 c2 0 0          (string bytes 4..5)
+    constexpr uint32_t kJoin = 0x05040100u;  // rest0 rest1 | next pair's t0 t1
+    constexpr uint32_t kTail = 0x06030204u;  // c0 t2 t3 c2        (string bytes 2..5)
+    b[0] = __builtin_amdgcn_perm(p0.c, p0.t, kHead);
+    b[1] = __builtin_amdgcn_perm(p1.t, __builtin_amdgcn_perm(p0.c, p0.t, kRest), kJoin);
+    b[2] = __builtin_amdgcn_perm(p1.c, p1.t, kTail);
+    b[3] = __builtin_amdgcn_perm(p2.c, p2.t, kHead);
+    b[4] = __builtin_amdgcn_perm(p3.t, __builtin_amdgcn_perm(p2.c, p2.t, kRest), kJoin);
+    b[5] = __builtin_amdgcn_perm(p3.c, p3.t, kTail);
+    uint32_t ab, cc;
+    digits_pair(x4, ab, cc);  // the ninth field alone: selector bytes a, b, c and 0x0C (-> 0x00)
+    b[6] = __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x47544341u, ab | (cc << 16) | 0x0C000000u);
 }
 
 // ---------------------------------------------------------------------------
@@ -162,14 +235,23 @@ __device__ __forceinline__ uint64_t word_from_slab(const uint32_t* my, uint32_t 
     uint32_t raw[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) raw[d] = my[q + d];
-    uint32_t c[7];
+    uint32_t x[7], c[7];
 #pragma unroll
-    for (int d = 0; d < 7; ++d) {
-        uint32_t x = (uint32_t)((((uint64_t)raw[d + 1] << 32) | raw[d]) >> s8);  // funnel shift right by the byte phase
-        if (d == 6) x &= 0x00FFFFFFu;                                             // bytes 24..26 only
-        c[d] = code5<STRICT>(x);
+    for (int d = 0; d < 7; ++d) x[d] = __builtin_amdgcn_alignbit(raw[d + 1], raw[d], s8);  // funnel shift right by the byte phase
+    if constexpr (STRICT) {
+#pragma unroll
+        for (int d = 0; d < 7; ++d) c[d] = code5_strict(x[d]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 7; ++d) c[d] = code5_table(x[d]);
+        // bytes >= 0x80 encode as 0 (n_to_bits2.rs:151): checked once per wave, fixed up only if seen
+        const uint32_t any = (x[0] | x[1] | x[2] | x[3] | x[4] | x[5] | x[6]) & 0x80808080u;
+        if (__builtin_amdgcn_ballot_w64(any != 0) != 0) {
+#pragma unroll
+            for (int d = 0; d < 7; ++d) c[d] = code5_clear_high(x[d], c[d]);
+        }
     }
-    return pack27(c);
+    return pack27(c);  // byte 27 (x[6]'s top byte, the next word's first letter) has weight 0
 }
 
 // Encode: WPL*108 coalesced 16-B loads into the wave's LDS slab; then, per round j, lane l
@@ -272,38 +354,26 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
     vu2 w2[WPL];
 #pragma unroll
     for (int j = 0; j < WPL; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
+    // per-lane constants: 1728 B per round is dword aligned, so every round has the same phase.
+    // The lane's 27 bytes start at byte 27*lane = dword q0, byte phase ph; shifting the string up by
+    // ph bytes is one v_perm_b32 per dword with selector bytes (4-ph, 5-ph, 6-ph, 7-ph) over
+    // {b[k], b[k-1]}.  The lane owns the complete dwords q0 .. ((27*(lane+1))>>2) - 1 (6 or 7 of them);
+    // the partial one behind them belongs to lane+1, which receives it through the shuffle.
+    const uint32_t byte0 = 27u * lane, q0 = byte0 >> 2, ph = byte0 & 3u;
+    const uint32_t sel = 0x07060504u - 0x01010101u * ph;
+    const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
 #pragma unroll
     for (int j = 0; j < WPL; ++j) {
-        const uint32_t lo = w2[j][0], hi = w2[j][1];
-        uint32_t L[9];  // 3 letters per triplet in the low 24 bits
-#define CNT_L(K) L[K] = letters5(digits3(field7<K>(lo, hi))) & 0x00FFFFFFu
-        CNT_L(0); CNT_L(1); CNT_L(2); CNT_L(3); CNT_L(4); CNT_L(5); CNT_L(6); CNT_L(7); CNT_L(8);
-#undef CNT_L
-        // the lane's 27 bytes as 7 dwords (b[6] holds 3 bytes), plus a zero guard
-        uint32_t b[8];
-        b[0] = L[0] | (L[1] << 24);
-        b[1] = (L[1] >> 8) | (L[2] << 16);
-        b[2] = (L[2] >> 16) | (L[3] << 8);
-        b[3] = L[4] | (L[5] << 24);
-        b[4] = (L[5] >> 8) | (L[6] << 16);
-        b[5] = (L[6] >> 16) | (L[7] << 8);
-        b[6] = L[8];
-        b[7] = 0;
-        // window of 8 aligned dwords starting at dword (27*lane)>>2, bytes shifted left by the phase
-        const uint32_t byte0 = 27u * lane, q0 = byte0 >> 2, s8 = (byte0 & 3u) * 8u;
-        // W = the 27-byte string shifted left by the phase: one v_alignbit_b32 per dword ({b[k],
-        // b[k-1]} >> (32 - s8)); a phase of 0 would need a shift of 32, which alignbit cannot do
+        uint32_t b[7];
+        decode27(w2[j][0], w2[j][1], b);
         uint32_t W[8];
-        const uint32_t sh = 32u - s8;
-        W[0] = b[0] << s8;
+        W[0] = __builtin_amdgcn_perm(b[0], 0u, sel);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) W[k] = s8 ? __builtin_amdgcn_alignbit(b[k], b[k - 1], sh) : b[k];
-        // complete dwords this lane owns: q0 .. ((27*(lane+1))>>2) - 1 (6 or 7 of them); the
-        // partial one after them belongs to lane+1, which receives it through the shuffle
-        const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
+        for (int k = 1; k < 7; ++k) W[k] = __builtin_amdgcn_perm(b[k], b[k - 1], sel);
+        W[7] = __builtin_amdgcn_perm(0u, b[6], sel);
         const uint32_t tail = cnt == 6 ? W[6] : W[7];
         const uint32_t prev_tail = __shfl_up(tail, 1, 64);
-        if (s8 != 0) W[0] |= prev_tail;  // lane 0 has s8 == 0
+        if (ph != 0) W[0] |= prev_tail;  // lane 0 has phase 0
         uint32_t* dst = my + kWaveDwords5 * j + q0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) dst[k] = W[k];

@@ -13,7 +13,7 @@ namespace cnt {
 
 // tile_nt = nucleotides per WAVE tile (WPL * 1728); a workgroup takes `waves` of them
 constexpr VariantDesc kEncode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 0: default
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 0: default
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5, 64, 0},   // 1
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},  // 2
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},  // 3
@@ -24,11 +24,16 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 8
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=nt st=sc1, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 9
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=nt st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 10
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 11
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 12
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 13
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 10 wg/CU", 2 * kWaveBytes5, 64, 10},  // 14
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 15: the default before the caps were re-swept
 };
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 0: default
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 0: default
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64, 0},   // 1
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 2
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 3
@@ -39,6 +44,14 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 8
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 9: as 0 without the XCD pairing
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=nt st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 10
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 11
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 12
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 13
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 14
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 10 wg/CU", 2 * kWaveBytes5, 64, 10},  // 15
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 16
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 17
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 18: the default before the caps were re-swept
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -64,7 +77,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
             case 3: CNT_ENC2(4, 2, kNT, kSC1); break;
             case 4: CNT_ENC2(1, 1, kNT, kSC1); break;
             case 5: CNT_ENC2(1, 2, 0, 0); break;
-            case 6: case 7: case 8: CNT_ENC2(1, 2, kNT, kSC1); break;
+            case 6: case 7: case 8: case 11: case 12: case 13: case 14: case 15: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             default: return 1;
@@ -75,13 +88,13 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
 }
 
 // The any-alignment companion of encode2 variant 0: `base` = input pointer rounded down to 128 B,
-// `phase` = the 1..127 bytes dropped.  Same LDS footprint per workgroup as variant 0 (24 wg/CU).
+// `phase` = the 1..127 bytes dropped.  Same LDS footprint per workgroup as variant 0 (15 wg/CU).
 constexpr uint32_t kWindowEncode2Tile = 2 * kWaveBytes5;  // nt per tile (128 words)
 constexpr uint32_t kWindowEncode2Slack = 128;             // bytes a tile may read behind its end
 template <bool STRICT>
 void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
-    const uint32_t lds = lds_for_cap(24) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
+    const uint32_t lds = lds_for_cap(kEncode2Variants[0].wg_cap) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         hipLaunchKernelGGL((n_to_bits2_window<kNT, kSC1, STRICT, 1>), dim3(grid_of(n)), dim3(64), lds, s,
@@ -104,14 +117,14 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
 #define CNT_DEC2(W, P, L, S) \
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
-            case 0: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 0: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
             case 2: CNT_DEC2(2, 2, 0, kAll); break;
             case 3: CNT_DEC2(4, 2, 0, kAll); break;
             case 4: CNT_DEC2(1, 1, 0, kAll); break;
             case 5: CNT_DEC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
-            case 9: CNT_DEC2(1, 2, 0, kAll); break;
+            case 9: case 13: case 14: case 15: CNT_DEC2(1, 2, 0, kAll); break;
             case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             default: return 1;
         }
