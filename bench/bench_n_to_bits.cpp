@@ -52,7 +52,8 @@ static void bench_function(const char* group, const char* name, size_t throughpu
            throughput_bytes / per / (double)(1ull << 30), throughput_bytes / per / 1e9);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const size_t max_log2 = argc > 1 ? (size_t)atoi(argv[1]) : 30;  // optional: largest host-tier size to run
     int ndev = 0;
     if (cnt_device_count(&ndev) != CNT_OK || ndev == 0) {
         fprintf(stderr, "no HIP device: this harness drives the GPU back-end only\n");
@@ -77,7 +78,8 @@ int main() {
         bench_function("bits_to_n2", "bits_to_n2_hip", 40000, [&] { g_sink += n_to_bits2::bits_to_n2_hip(bits, 40000).back(); });
     }
     // ---- the same drop-in calls at sizes where PCIe, not launch latency, is the bound ---------
-    for (size_t log2 : {20, 26, 30}) {
+    for (size_t log2 : {16, 18, 20, 22, 24, 26, 30}) {
+        if (log2 > max_log2) continue;
         const size_t len = (size_t)1 << log2;
         std::vector<uint8_t> n(len);
         uint64_t x = 0x9E3779B97F4A7C15ull;

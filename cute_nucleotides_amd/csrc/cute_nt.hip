@@ -148,12 +148,15 @@ struct DevCtx {
     void* d_out[2] = {nullptr, nullptr};
     uint8_t* h_in[2] = {nullptr, nullptr};   // pinned
     uint8_t* h_out[2] = {nullptr, nullptr};  // pinned
+    void* hd_in = nullptr;   // h_in[0] / h_out[0] as the device sees them (zero-copy path for small inputs)
+    void* hd_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
 
     int ensure(size_t need_in, size_t need_out) {
         for (int i = 0; i < 2; ++i)
             if (!stream[i]) HIP_TRY(hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking));
         if (need_in > cap_in) {
+            cap_in = 0;  // a failure below must not leave a stale capacity behind
             for (int i = 0; i < 2; ++i) {
                 if (d_in[i]) HIP_TRY(hipFree(d_in[i]));
                 if (h_in[i]) HIP_TRY(hipHostFree(h_in[i]));
@@ -162,9 +165,11 @@ struct DevCtx {
                 HIP_TRY(hipMalloc(&d_in[i], need_in));
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_in[i]), need_in, hipHostMallocDefault));
             }
+            HIP_TRY(hipHostGetDevicePointer(&hd_in, h_in[0], 0));
             cap_in = need_in;
         }
         if (need_out > cap_out) {
+            cap_out = 0;
             for (int i = 0; i < 2; ++i) {
                 if (d_out[i]) HIP_TRY(hipFree(d_out[i]));
                 if (h_out[i]) HIP_TRY(hipHostFree(h_out[i]));
@@ -173,6 +178,7 @@ struct DevCtx {
                 HIP_TRY(hipMalloc(&d_out[i], need_out));
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_out[i]), need_out, hipHostMallocDefault));
             }
+            HIP_TRY(hipHostGetDevicePointer(&hd_out, h_out[0], 0));
             cap_out = need_out;
         }
         return CNT_OK;
@@ -221,6 +227,17 @@ thread_local ThreadCtx t_ctx;
 // MiB of pinned staging and as much device scratch per calling thread.
 constexpr size_t kChunkNt = (size_t)16 << 20;       // multiple of 32
 constexpr size_t kChunkNt5 = (size_t)27 * 512 << 10;  // 27-nt words: 512 Ki words per chunk (13.5 Mi nt)
+
+// Small host-tier calls skip the two DMA submissions: the kernels read the pinned staging buffer and
+// write the pinned result buffer directly over PCIe (zero-copy), so a call is memcpy, one launch, one
+// stream sync, memcpy.  CNT_ZEROCOPY_MAX_NT overrides the size limit (0 disables the path).
+size_t zero_copy_max_nt() {
+    static const size_t v = [] {
+        const char* e = getenv("CNT_ZEROCOPY_MAX_NT");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 20;
+    }();
+    return v;
+}
 
 // ---- device-tier bodies (shared by every tier) ------------------------------------
 // Alignment plan (profiles/r01_align_lab_*.json): stores that are not 64-B aligned cost ~30 %, loads
@@ -414,6 +431,17 @@ int decode2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsig
 typedef int (*enc_fn)(const void*, size_t, void*, size_t, unsigned, hipStream_t);
 typedef int (*dec_fn)(const void*, size_t, size_t, void*, unsigned, hipStream_t);
 
+// Chunk size of the 2-slot pipeline: the full chunk for big inputs; mid-size inputs are cut into
+// about four pieces (>= 256 Ki words' worth) so that staging copies and DMA overlap at all.
+size_t pipeline_chunk(size_t n_len, size_t unit_nt, size_t chunk_nt) {
+    const size_t whole = (n_len + unit_nt - 1) / unit_nt * unit_nt;
+    if (whole >= 4 * chunk_nt) return chunk_nt;
+    const size_t gran = unit_nt * 8192;  // 256 Ki nt (2-bit) / 216 Ki nt (5-letter)
+    size_t c = ((whole / 4 + gran - 1) / gran) * gran;
+    if (c < gran) c = gran;
+    return std::min(std::min(c, chunk_nt), whole);
+}
+
 int host_encode(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags, size_t unit_nt,
                 size_t chunk_nt, enc_fn fn) {
     const size_t words = (n_len + unit_nt - 1) / unit_nt;
@@ -423,7 +451,15 @@ int host_encode(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words,
     if (!n || !out) return CNT_EINVAL;
     DevCtx* c = nullptr;
     CNT_TRY(t_ctx.get(&c));
-    const size_t chunk = std::min(chunk_nt, (n_len + unit_nt - 1) / unit_nt * unit_nt);
+    if (n_len <= zero_copy_max_nt()) {
+        CNT_TRY(c->ensure(words * unit_nt, words * 8));
+        memcpy(c->h_in[0], n, n_len);
+        CNT_TRY(fn(c->hd_in, n_len, c->hd_out, words, flags, c->stream[0]));
+        HIP_TRY(hipStreamSynchronize(c->stream[0]));
+        memcpy(out, c->h_out[0], words * 8);
+        return CNT_OK;
+    }
+    const size_t chunk = pipeline_chunk(n_len, unit_nt, chunk_nt);
     CNT_TRY(c->ensure(chunk, chunk / unit_nt * 8));
     // 2-slot pipeline: while slot A's H2D / kernel / D2H run on its stream, the host copies slot B's
     // finished output to the caller and stages slot B's next input.
@@ -469,7 +505,16 @@ int host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, si
     if (!bits || !out) return CNT_EINVAL;
     DevCtx* c = nullptr;
     CNT_TRY(t_ctx.get(&c));
-    const size_t chunk = std::min(chunk_nt, (len + unit_nt - 1) / unit_nt * unit_nt);
+    if (len <= zero_copy_max_nt()) {
+        const size_t w = (len + unit_nt - 1) / unit_nt;
+        CNT_TRY(c->ensure(w * 8, len + 32));
+        memcpy(c->h_in[0], bits, w * 8);
+        CNT_TRY(fn(c->hd_in, w, len, c->hd_out, 0, c->stream[0]));
+        HIP_TRY(hipStreamSynchronize(c->stream[0]));
+        memcpy(out, c->h_out[0], len);
+        return CNT_OK;
+    }
+    const size_t chunk = pipeline_chunk(len, unit_nt, chunk_nt);
     // +32: the reference's SIMD decoders may store whole 32-B blocks; ours never writes past
     // `len`, the slack only keeps device stores inside the scratch.
     CNT_TRY(c->ensure(chunk / unit_nt * 8, chunk + 32));
