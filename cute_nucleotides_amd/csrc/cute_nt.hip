@@ -52,6 +52,9 @@ std::atomic<int> g_encode_variant{0};
 std::atomic<int> g_decode_variant{0};
 std::atomic<int> g_encode2_variant{0};
 std::atomic<int> g_decode2_variant{0};
+// inputs up to this many nucleotides that would need a second (ragged-end) launch anyway go through
+// the generic kernel alone: one launch instead of two or three
+std::atomic<int> g_small_nt{1 << 17};
 
 inline unsigned generic_grid(uint64_t items) {
     uint64_t b = (items + kBlock - 1) / kBlock;
@@ -264,6 +267,11 @@ int encode_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, uns
         else
             hipLaunchKernelGGL((n_to_bits_generic<false>), dim3(g), dim3(kBlock), 0, s, n, nt_end, out, first_word, end_word);
     };
+    if (n_len <= (size_t)g_small_nt.load(std::memory_order_relaxed) && (n_len % kWindowEncodeTile) != 0) {
+        generic(n_len, 0, words);
+        HIP_TRY(hipGetLastError());
+        return CNT_OK;
+    }
     // head: words until the output is 64-B aligned (enough for the stores; peeling further would only
     // push the input off its own alignment); 256 nt more if the input phase is not zero, so that
     // the window kernel's rounded-down loads stay inside the caller's buffer
@@ -305,6 +313,12 @@ int decode_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsign
     const size_t used_words = cnt_words_for(len);
     const uint64_t* bits = static_cast<const uint64_t*>(d_bits);
     uint8_t* out = static_cast<uint8_t*>(d_out);
+    if (len <= (size_t)g_small_nt.load(std::memory_order_relaxed) && (len % kShiftedDecodeTile) != 0) {
+        hipLaunchKernelGGL(bits_to_n_generic, dim3(generic_grid(used_words)), dim3(kBlock), 0, s, bits, (uint64_t)len, out,
+                           (uint64_t)0, (uint64_t)used_words);
+        HIP_TRY(hipGetLastError());
+        return CNT_OK;
+    }
     // head: nucleotides until the output is on a 128-B line -- for large buffers on a 4-KiB boundary,
     // so that every tile is one aligned 4-KiB piece (worth 2-5 %)
     const uint64_t grain = len >= ((uint64_t)1 << 20) ? 4096 : 128;
@@ -364,6 +378,11 @@ int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, un
         else
             hipLaunchKernelGGL((n_to_bits2_generic<false>), dim3(g), dim3(kBlock), 0, s, n, nt_end, out, first_word, end_word);
     };
+    if (n_len <= (size_t)g_small_nt.load(std::memory_order_relaxed) && (n_len % kWindowEncode2Tile) != 0) {
+        generic(n_len, 0, words);
+        HIP_TRY(hipGetLastError());
+        return CNT_OK;
+    }
     uint64_t head_words = ((64 - (reinterpret_cast<uintptr_t>(d_out) & 63)) & 63) >> 3;
     const uint32_t phase = (uint32_t)((reinterpret_cast<uintptr_t>(n) + 27 * head_words) & 127);
     if (phase && head_words < 5) head_words += 8;  // 64 B of output; >= 127 B of input in front of the first window
@@ -408,6 +427,11 @@ int decode2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsig
         hipLaunchKernelGGL(bits_to_n2_generic, dim3(generic_grid(end_word - first_word)), dim3(kBlock), 0, s, bits, nt_end, out,
                            first_word, end_word);
     };
+    if (len <= (size_t)g_small_nt.load(std::memory_order_relaxed) && (len % kWindowEncode2Tile) != 0) {
+        generic(len, 0, used_words);
+        HIP_TRY(hipGetLastError());
+        return CNT_OK;
+    }
     const uint64_t head_words = (19 * ((128 - (reinterpret_cast<uintptr_t>(d_out) & 127)) & 127)) & 127;
     uint64_t main_words = 0;
     if (len > 27 * head_words) {
@@ -811,6 +835,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "decode2")) {
         if (value < 0 || value >= kNumDecode2Variants) return CNT_EINVAL;
         g_decode2_variant.store(value);
+    } else if (!strcmp(key, "small_nt")) {
+        if (value < 0) return CNT_EINVAL;
+        g_small_nt.store(value);
     } else {
         return CNT_EINVAL;
     }
@@ -823,6 +850,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "decode")) *value = g_decode_variant.load();
     else if (!strcmp(key, "encode2")) *value = g_encode2_variant.load();
     else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
+    else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;

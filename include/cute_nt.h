@@ -100,7 +100,8 @@ int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_
 
 /* ---- device-pointer tier: what the roofline metric measures ------------------- */
 /* Pointers are device memory on the calling thread's current device.  `stream`
- * is a hipStream_t (NULL = the legacy default stream); the call only enqueues.
+ * is a hipStream_t (NULL = the legacy default stream); the call only enqueues
+ * (no synchronisation, no allocation: it can be captured into a HIP graph).
  * ASCII pointers may have ANY alignment, word pointers 8 bytes; all combinations
  * run within a few percent of the aligned speed (a short head is peeled so the
  * stores are line-aligned, the loads absorb the phase), both codecs.
@@ -147,7 +148,9 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
 /* Kernel-variant override for tuning / A-B runs (bench/ only; variant 0 is the shipped,
  * measured-best default).  key "encode" / "decode" (2-bit codec), "encode2" / "decode2"
  * (5-letter codec): value = variant index; cnt_get_tuning also answers "<key>_variants"
- * (the counts).
+ * (the counts).  key "small_nt": inputs of at most this many nucleotides that are not a whole
+ * number of tiles take ONE generic-kernel launch instead of tiles + ragged end (default 2^17,
+ * 0 = never).
  * cnt_tuning_name returns the variant's description (NULL when out of range).
  * CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);

@@ -37,7 +37,7 @@ def cn():
 def tuning():
     from cute_nucleotides_amd import devutil
 
-    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode")}
+    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "small_nt")}
     yield devutil
     for k, v in saved.items():
         devutil.set_tuning(k, v)
@@ -100,6 +100,7 @@ def test_variant_tables(tuning):
 def test_encode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, variant):
     torch = torch_cuda
     tuning.set_tuning("encode", variant)
+    tuning.set_tuning("small_nt", 0)
     for n_len in (2048, 16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20), 2048 * 16 * 5 + 2048 * 3 + 17):
         n = _rand_valid(n_len, 7 * n_len + variant)
         want = oracle.n_to_bits_lut(n)
@@ -171,6 +172,7 @@ def test_decode_matches_lut_oracle_host_tier(cn, oracle, n_len):
 def test_decode_every_variant_device_tier(cn, oracle, torch_cuda, tuning, variant):
     torch = torch_cuda
     tuning.set_tuning("decode", variant)
+    tuning.set_tuning("small_nt", 0)
     rng = np.random.default_rng(variant)
     for n_len in (2048, 16384, 65536 + 31, (1 << 21) + 4097, 3 * (1 << 20), 2048 * 16 * 5 + 2048 * 3 + 17):
         bits = rng.integers(0, 2**64, (n_len + 31) // 32, dtype=np.uint64)
@@ -348,10 +350,11 @@ ALIGN_OUT_WORD_OFFS = [0, 1, 2, 3, 7, 8, 15]
 
 
 @pytest.mark.parametrize("strict", [False, True])
-def test_encode_alignment_matrix(cn, oracle, torch_cuda, strict):
+def test_encode_alignment_matrix(cn, oracle, torch_cuda, tuning, strict):
     """Every input byte phase x output word phase, sizes on both sides of the peel/tile/guard
     boundaries, guard values around the output: bit-exact and nothing written outside."""
     torch = torch_cuda
+    tuning.set_tuning("small_nt", 0)  # small ragged inputs would otherwise take the generic kernel alone
     if True:
         sizes = [2048 * 3 + 144 + 5, 512 + 2048 + 143, 512 + 2048 + 144, 512 + 2048 + 145, 40000, 100003]
         big = _rand_valid(max(sizes), 77) if not strict else np.random.default_rng(78).integers(0, 256, max(sizes), dtype=np.uint8)
@@ -373,9 +376,10 @@ def test_encode_alignment_matrix(cn, oracle, torch_cuda, strict):
                     assert np.array_equal(got[8 + oo : 8 + oo + words].view(np.uint64), want), (n_len, io, oo)
 
 
-def test_decode_alignment_matrix(cn, oracle, torch_cuda):
+def test_decode_alignment_matrix(cn, oracle, torch_cuda, tuning):
     """Every output byte phase (mod 128) x packed-word phase, lengths around the boundaries."""
     torch = torch_cuda
+    tuning.set_tuning("small_nt", 0)
     bits = np.random.default_rng(5).integers(0, 2**64, 4000, dtype=np.uint64)
     dbuf = torch.zeros(bits.size + 16, dtype=torch.int64, device="cuda")
     obuf = torch.empty(bits.size * 32 + 512, dtype=torch.uint8, device="cuda")
@@ -411,6 +415,34 @@ def test_decode_large_buffer_4k_head(cn, oracle, torch_cuda):
             got = obuf.cpu().numpy()
             assert (got[: base + oo] == 0x2A).all() and (got[base + oo + length :] == 0x2A).all(), (oo, length)
             assert np.array_equal(got[base + oo : base + oo + length], want[:length]), (oo, length)
+
+
+@pytest.mark.parametrize("small_nt", [0, 1 << 17])
+def test_device_tier_is_graph_capturable(cn, oracle, torch_cuda, tuning, small_nt):
+    """The device tier only enqueues (no sync, no allocation): an encode + decode pair recorded
+    into a HIP graph replays correctly on new contents of the same buffers."""
+    torch = torch_cuda
+    tuning.set_tuning("small_nt", small_nt)
+    n_len = 40000 + 13  # the reference's bench size plus a ragged tail: tile, head and tail kernels all in the graph
+    d_in = torch.zeros(n_len + 3, dtype=torch.uint8, device="cuda")[3:]  # and a misaligned input
+    d_pk = torch.zeros((n_len + 31) // 32, dtype=torch.int64, device="cuda")
+    d_out = torch.zeros(n_len, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # warm-up outside capture (module load)
+        cn.n_to_bits_dev(d_in, out=d_pk)
+        cn.bits_to_n_dev(d_pk, n_len, out=d_out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cn.n_to_bits_dev(d_in, out=d_pk)
+        cn.bits_to_n_dev(d_pk, n_len, out=d_out)
+    for seed in (1, 2, 3):
+        n = _rand_valid(n_len, seed)
+        d_in.copy_(torch.from_numpy(n))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_pk.cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(n))
+        assert bytes(d_out.cpu().numpy()) == bytes(n).upper().replace(b"U", b"T")
 
 
 # ---- boundary behaviour of the C ABI -------------------------------------------------------

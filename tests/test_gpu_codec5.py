@@ -10,6 +10,17 @@ SIZES = [1, 2, 3, 4, 5, 26, 27, 28, 53, 54, 55, 80, 81, 82, 6911, 6912, 6913, 69
          (1 << 22) + 11]
 
 
+@pytest.fixture()
+def no_small_path():
+    """small ragged inputs normally take the generic kernel alone: switch that off to reach the tiles"""
+    from cute_nucleotides_amd import devutil
+
+    saved = devutil.get_tuning("small_nt")
+    devutil.set_tuning("small_nt", 0)
+    yield
+    devutil.set_tuning("small_nt", saved)
+
+
 @pytest.fixture(scope="module")
 def cn():
     import torch
@@ -31,9 +42,13 @@ def test_encode_decode_host_tier(cn, oracle, n_len):
     assert bytes(back) == bytes(n).upper().replace(b"U", b"T")
 
 
-def test_device_tier_aligned_unaligned_and_overrun(cn, oracle):
+@pytest.mark.parametrize("small_nt", [0, 1 << 17])
+def test_device_tier_aligned_unaligned_and_overrun(cn, oracle, small_nt):
     import torch
 
+    from cute_nucleotides_amd import devutil
+
+    devutil.set_tuning("small_nt", small_nt)
     n_len = 6912 * 5 + 100
     n = oracle.fill_random_acgtn(n_len, 5)
     want = oracle.n_to_bits2_lut(n)
@@ -56,10 +71,11 @@ def test_device_tier_aligned_unaligned_and_overrun(cn, oracle):
             assert np.array_equal(got[off : off + length], oracle.bits_to_n2_lut(want, length)), (length, off)
     with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
         cn.bits_to_n2_dev(dbits, want.size * 27 + 1)
+    devutil.set_tuning("small_nt", 1 << 17)
 
 
 @pytest.mark.parametrize("strict", [False, True])
-def test_encode_alignment_matrix(cn, oracle, strict):
+def test_encode_alignment_matrix(cn, oracle, no_small_path, strict):
     """Any input byte phase x output word phase (head peel + n_to_bits2_window), sizes around the
     peel / tile / slack boundaries, guard words around the output."""
     import torch
@@ -85,7 +101,7 @@ def test_encode_alignment_matrix(cn, oracle, strict):
                 assert np.array_equal(got[8 + oo : 8 + oo + want.size].view(np.uint64), want), (n_len, io, oo)
 
 
-def test_decode_alignment_matrix(cn, oracle):
+def test_decode_alignment_matrix(cn, oracle, no_small_path):
     """Every output phase mod 128 (the head is 19 * (-phase) mod 128 whole words) x packed-word phase."""
     import torch
 

@@ -18,8 +18,19 @@ def _lengths(rng, k):
     return out
 
 
+@pytest.fixture(params=[0, 1 << 17], ids=["tiles", "small-path"])
+def small_nt(request):
+    """with and without the single-launch path for small ragged inputs (tuning key small_nt)"""
+    from cute_nucleotides_amd import devutil
+
+    saved = devutil.get_tuning("small_nt")
+    devutil.set_tuning("small_nt", request.param)
+    yield request.param
+    devutil.set_tuning("small_nt", saved)
+
+
 @pytest.mark.parametrize("seed", range(4))
-def test_two_bit_codec_fuzz(oracle, seed):
+def test_two_bit_codec_fuzz(oracle, small_nt, seed):
     import torch
 
     import cute_nucleotides_amd as cn
@@ -57,7 +68,7 @@ def test_two_bit_codec_fuzz(oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_five_letter_codec_fuzz(oracle, seed):
+def test_five_letter_codec_fuzz(oracle, small_nt, seed):
     import torch
 
     import cute_nucleotides_amd as cn
