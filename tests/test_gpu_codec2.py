@@ -236,6 +236,27 @@ def test_sharded_tier_single_device(cn, oracle):
 
     with pytest.raises(CuteNtError):
         cn.n_to_bits_hip_sharded(n, ndev=torch.cuda.device_count() + 1)
+    # the per-device workers are persistent: repeated calls, a shutdown in between (which releases
+    # the workers' streams and staging), concurrent callers (they queue on the pool)
+    from cute_nucleotides_amd import _lib
+    import threading
+
+    for _ in range(3):
+        assert np.array_equal(cn.n_to_bits_hip_sharded(n, ndev=1), bits)
+    assert _lib.lib().cnt_shutdown() == 0
+    assert np.array_equal(cn.n_to_bits_hip_sharded(n, ndev=1), bits)
+    bad = []
+
+    def worker(seed):
+        m = oracle.fill_random_acgt(300000 + seed, seed)
+        for _ in range(4):
+            if not np.array_equal(cn.n_to_bits_hip_sharded(m, ndev=1), oracle.n_to_bits_lut(m)):
+                bad.append(seed)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
 
 
 # ---- device utilities used by the large-size checks --------------------------------------
