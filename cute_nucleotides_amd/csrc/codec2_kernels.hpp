@@ -21,8 +21,9 @@
 //     write-through non-temporal (sc0|sc1|nt) stores for both (for encode sc1 alone
 //     is as fast, but leaves the packed buffer in a state that slows the decode that
 //     follows by 1.3 %);
-//   * letting each XCD (block b runs on XCD b%8) own 4 KiB-contiguous pieces of
-//     the wide side is worth 1-2 %;
+//   * letting each XCD (block b runs on XCD b%8) take its READ stream in whole 4-KiB pieces --
+//     two 2-KiB ASCII tiles per turn for encode, four 4-KiB output tiles (= 4 KiB of packed
+//     words) per turn for decode -- is worth 1-3 %; other group sizes lose;
 //   * capping residency at ~24 waves per CU (dummy LDS) is worth another 2-3 %.
 // Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
 // per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)

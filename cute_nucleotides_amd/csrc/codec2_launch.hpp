@@ -105,7 +105,7 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
 
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
-    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 0: default
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 0: default
     {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16, 256, 0},        // 1
     {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16, 64, 0},  // 2
     {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16, 256, 0},                   // 3: the first shape tried
@@ -120,6 +120,9 @@ constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=128 U=2 xcd-pairs ld=sc0|nt st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 12
     {"stream B=128 U=2 xcd-pairs ld=plain st=sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 13
     {"stream B=128 U=2 xcd-pairs ld=sc1 st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 14
+    {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 15: the default before the XCD group size was re-swept
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 14 wg/CU", 128 * 2 * 16, 128, 14},  // 16
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 15 wg/CU", 128 * 2 * 16, 128, 15},  // 17
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -139,7 +142,7 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
 #define CNT_DEC_STREAM(B, U, C, L, S) \
     hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), lds, s, in, out, n_tiles)
     switch (variant) {
-        case 0: CNT_DEC_STREAM(128, 2, 2, 0, kAll); break;
+        case 0: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
         case 1: CNT_DEC_STREAM(256, 2, 1, 0, kAll); break;
         case 2: CNT_DEC_STREAM(64, 2, 2, 0, kAll); break;
         case 3: CNT_DEC_STREAM(256, 2, 1, kNT, kNT); break;
@@ -154,6 +157,8 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 12: CNT_DEC_STREAM(128, 2, 2, kSC0 | kNT, kAll); break;
         case 13: CNT_DEC_STREAM(128, 2, 2, 0, kSC1 | kNT); break;
         case 14: CNT_DEC_STREAM(128, 2, 2, kSC1, kAll); break;
+        case 15: CNT_DEC_STREAM(128, 2, 2, 0, kAll); break;
+        case 16: case 17: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
         default: return 1;
     }
     }
@@ -169,7 +174,7 @@ inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, 
     const uint32_t lds = lds_for_cap(13);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
-        hipLaunchKernelGGL((bits_to_n_shifted<128, 2, 2, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(128), lds, s,
+        hipLaunchKernelGGL((bits_to_n_shifted<128, 2, 4, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(128), lds, s,
                            in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, n_tiles, sh);
     }
 }
