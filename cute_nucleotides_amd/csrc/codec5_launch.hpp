@@ -33,7 +33,7 @@ constexpr VariantDesc kEncode2Variants[] = {
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
-    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 0: default
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 0: default
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64, 0},   // 1
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 2
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 3
@@ -52,6 +52,9 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 16
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 17
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 18: the default before the caps were re-swept
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 19: the default before the XCD group size was re-swept
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc0|sc1|nt, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 20
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc0|sc1|nt, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 21
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -117,7 +120,8 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
 #define CNT_DEC2(W, P, L, S) \
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
-            case 0: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
             case 2: CNT_DEC2(2, 2, 0, kAll); break;
             case 3: CNT_DEC2(4, 2, 0, kAll); break;
