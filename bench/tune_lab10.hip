@@ -86,11 +86,13 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL((n_to_bits_stream<256, 4, 1, 0, 0, false>), dim3((unsigned)(N / 16384)), dim3(256), 0, s, d_in, d_packed, N / 16384);
     CK(hipStreamSynchronize(s));
     constexpr int A = kSC0 | kSC1 | kNT;
-    add<128, 2, 2, 0, 0, A>(13);  // shipped decode
-    add<128, 2, 4, 0, 0, A>(14);
-    add<128, 2, 4, 0, 0, A>(15);
-    for (int k : {22, 23, 24, 26}) { add_enc<64, 2, 2, kNT, A>(k); add_enc<64, 2, 4, kNT, A>(k); add_enc<64, 2, 8, kNT, A>(k); add_enc<64, 2, 16, kNT, A>(k); }
-    for (int k : {11, 12, 13}) { add_enc<128, 2, 1, kNT, A>(k); add_enc<128, 2, 2, kNT, A>(k); add_enc<128, 2, 4, kNT, A>(k); add_enc<128, 2, 8, kNT, A>(k); }
+    add<128, 2, 2, 0, 0, A>(13);  // pairs
+    add<128, 2, 4, 0, 0, A>(13);  // quads (shipped)
+    for (int k : {6, 7}) { add<256, 2, 2, 0, 0, A>(k); add<256, 2, 1, 0, 0, A>(k); }
+    for (int k : {3, 4}) { add<512, 2, 1, 0, 0, A>(k); }
+    for (int k : {13, 14}) { add<256, 1, 4, 0, 0, A>(k); }
+    for (int k : {26, 28}) { add<64, 2, 8, 0, 0, A>(k); add<128, 1, 8, 0, 0, A>(k); }
+    for (int k : {12, 13, 14}) { add<64, 4, 4, 0, 0, A>(k); }
     uint64_t ref_d = 0, ref_e = checksum(d_packed, N / 32, s); bool have = false;
     for (auto& v : vs) {
         if (v.is_enc) {
