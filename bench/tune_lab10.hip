@@ -53,6 +53,31 @@ __global__ __launch_bounds__(BLOCK) void enc10(const uint8_t* __restrict__ in, u
     for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b32(enc16<false>(v[u]), rout, (u * BLOCK + tid) * 4, 0, SAUX);
 }
 
+// which of the 8 chunks of a group the XCD slot (b % 8) takes: (slot + ROT) % 8 or slot ^ XM
+template <int C, int ROT, int XM>
+__device__ __forceinline__ uint64_t tile_rot(uint64_t b, uint64_t n_tiles) {
+    constexpr uint64_t G = 8 * C;
+    const uint64_t g = b / G;
+    if ((g + 1) * G > n_tiles) return b;
+    const uint64_t r = b % G;
+    const uint64_t slot = ((r % 8 + ROT) % 8) ^ XM;
+    return g * G + slot * C + (r / 8);
+}
+template <int ROT, int XM>
+__global__ __launch_bounds__(64) void enc_rot(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    extern __shared__ uint32_t pad[];
+    const uint64_t t = tile_rot<2, ROT, XM>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * 2048, 2048);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * 512, 512);
+    const uint32_t tid = threadIdx.x;
+    u32x4 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * 64 + tid) * 16, 0, kNT));
+    if (n_tiles == 0xFFFFFFFFFFFFFFFFull) pad[tid] = v[0].x;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_buffer_store_b32(enc16<false>(v[u]), rout, (u * 64 + tid) * 4, 0, kSC0 | kSC1 | kNT);
+}
+
 struct Variant { std::string name; std::function<void(hipStream_t)> launch; std::vector<float> ms; bool is_enc = false; };
 static uint8_t *d_in, *d_packed, *d_out;
 static uint64_t N;
@@ -68,6 +93,11 @@ template <int B, int U, int C, int L, int S> void add_enc(int cap) {
     size_t lds = cap ? (size_t)(163840 / cap) / 256 * 256 : 0;
     CK(hipFuncSetAttribute((const void*)enc10<B, U, C, L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((enc10<B, U, C, L, S>), dim3((unsigned)t), dim3(B), lds, s, d_in, d_packed, t); }, {}, true}); }
+
+template <int ROT, int XM> void add_rot() {
+    char n[96]; snprintf(n, 96, "enc B=64 U=2 C=2 rot=%d xor=%d cap=23", ROT, XM); uint64_t t = N / 2048;
+    size_t lds = (size_t)(163840 / 23) / 256 * 256;
+    vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((enc_rot<ROT, XM>), dim3((unsigned)t), dim3(64), lds, s, d_in, d_packed, t); }, {}, true}); }
 
 static uint64_t checksum(const void* p, uint64_t words, hipStream_t s) {
     static unsigned long long* d_sum = nullptr;
@@ -86,13 +116,9 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL((n_to_bits_stream<256, 4, 1, 0, 0, false>), dim3((unsigned)(N / 16384)), dim3(256), 0, s, d_in, d_packed, N / 16384);
     CK(hipStreamSynchronize(s));
     constexpr int A = kSC0 | kSC1 | kNT;
-    add<128, 2, 2, 0, 0, A>(13);  // pairs
-    add<128, 2, 4, 0, 0, A>(13);  // quads (shipped)
-    for (int k : {6, 7}) { add<256, 2, 2, 0, 0, A>(k); add<256, 2, 1, 0, 0, A>(k); }
-    for (int k : {3, 4}) { add<512, 2, 1, 0, 0, A>(k); }
-    for (int k : {13, 14}) { add<256, 1, 4, 0, 0, A>(k); }
-    for (int k : {26, 28}) { add<64, 2, 8, 0, 0, A>(k); add<128, 1, 8, 0, 0, A>(k); }
-    for (int k : {12, 13, 14}) { add<64, 4, 4, 0, 0, A>(k); }
+    add<128, 2, 4, 0, 0, A>(13);  // shipped decode
+    add_rot<0, 0>(); add_rot<1, 0>(); add_rot<2, 0>(); add_rot<3, 0>(); add_rot<4, 0>(); add_rot<5, 0>(); add_rot<6, 0>(); add_rot<7, 0>();
+    add_rot<0, 1>(); add_rot<0, 2>(); add_rot<0, 3>(); add_rot<0, 4>(); add_rot<0, 5>(); add_rot<0, 6>(); add_rot<0, 7>();
     uint64_t ref_d = 0, ref_e = checksum(d_packed, N / 32, s); bool have = false;
     for (auto& v : vs) {
         if (v.is_enc) {
