@@ -188,11 +188,24 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group(backend=backend)
+        # gloo announces its connections on STDOUT from C++ ("[Gloo] Rank 0 is connected to ..."); the
+        # contract is ONE JSON line there, so the process-level stdout points at stderr while the group
+        # comes up (and for the whole run on ranks > 0, which print nothing themselves)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+            else:
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                dist.init_process_group(backend=backend)
+            dist.barrier()  # first collective: lazy connection chatter happens here, not later
+        finally:
+            sys.stdout.flush()
+            if rank == 0:
+                os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     import cute_nucleotides_amd as cn
     from cute_nucleotides_amd import devutil, sharding

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _last_json(text):
-    lines = [l for l in text.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, text  # rank 0 prints ONE JSON line
+    lines = [l for l in text.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), text  # stdout is ONE JSON line and nothing else
     return json.loads(lines[0])
 
 
