@@ -117,8 +117,11 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     constexpr int A = kSC0 | kSC1 | kNT;
     add<128, 2, 4, 0, 0, A>(13);  // shipped decode
-    add_rot<0, 0>(); add_rot<1, 0>(); add_rot<2, 0>(); add_rot<3, 0>(); add_rot<4, 0>(); add_rot<5, 0>(); add_rot<6, 0>(); add_rot<7, 0>();
-    add_rot<0, 1>(); add_rot<0, 2>(); add_rot<0, 3>(); add_rot<0, 4>(); add_rot<0, 5>(); add_rot<0, 6>(); add_rot<0, 7>();
+    add<128, 2, 4, 1, 0, A>(13); add<128, 2, 4, 1, 0, A>(14); add<128, 2, 4, 0, 0, A>(14);
+    add_enc<64, 2, 2, kNT, A>(23);  // shipped encode
+    for (int k : {0, 28}) { add_enc<64, 1, 4, kNT, A>(k); add_enc<128, 1, 2, kNT, A>(k / 2); add_enc<256, 1, 1, kNT, A>(k / 4); }
+    for (int k : {10, 11, 12}) { add_enc<128, 2, 1, kNT, A>(k); }
+    for (int k : {5, 6}) { add_enc<256, 2, 1, kNT, A>(k); add_enc<256, 1, 1, kNT, A>(k); }
     uint64_t ref_d = 0, ref_e = checksum(d_packed, N / 32, s); bool have = false;
     for (auto& v : vs) {
         if (v.is_enc) {
