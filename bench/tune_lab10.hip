@@ -99,6 +99,34 @@ template <int ROT, int XM> void add_rot() {
     size_t lds = (size_t)(163840 / 23) / 256 * 256;
     vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((enc_rot<ROT, XM>), dim3((unsigned)t), dim3(64), lds, s, d_in, d_packed, t); }, {}, true}); }
 
+
+// map2: one input page per XCD turn as shipped, but the four pages whose packed output shares one
+// 4-KiB output page go to the SAME XCD in four consecutive turns (groups of 64 tiles = 32 pages)
+template <int MODE>
+__global__ __launch_bounds__(64) void enc_map2(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    extern __shared__ uint32_t pad[];
+    uint64_t t = blockIdx.x;
+    const uint64_t g = t / 64;
+    if ((g + 1) * 64 <= n_tiles) {
+        const uint32_t r = t % 64, turn = r / 16, slot = r % 8, half = (r % 16) / 8;
+        const uint32_t page = MODE == 0 ? 4 * slot + turn : 4 * slot + ((turn + slot) & 3);
+        t = g * 64 + 2 * page + half;
+    }
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * 2048, 2048);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * 512, 512);
+    const uint32_t tid = threadIdx.x;
+    u32x4 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * 64 + tid) * 16, 0, kNT));
+    if (n_tiles == 0xFFFFFFFFFFFFFFFFull) pad[tid] = v[0].x;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_buffer_store_b32(enc16<false>(v[u]), rout, (u * 64 + tid) * 4, 0, kSC0 | kSC1 | kNT);
+}
+template <int MODE> void add_map2(int cap) {
+    char n[96]; snprintf(n, 96, "enc map2 mode=%d cap=%d", MODE, cap); uint64_t t = N / 2048;
+    size_t lds = (size_t)(163840 / cap) / 256 * 256;
+    vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((enc_map2<MODE>), dim3((unsigned)t), dim3(64), lds, s, d_in, d_packed, t); }, {}, true}); }
+
 static uint64_t checksum(const void* p, uint64_t words, hipStream_t s) {
     static unsigned long long* d_sum = nullptr;
     if (!d_sum) CK(hipMalloc(&d_sum, 8));
@@ -117,11 +145,9 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     constexpr int A = kSC0 | kSC1 | kNT;
     add<128, 2, 4, 0, 0, A>(13);  // shipped decode
-    add<128, 2, 4, 1, 0, A>(13); add<128, 2, 4, 1, 0, A>(14); add<128, 2, 4, 0, 0, A>(14);
     add_enc<64, 2, 2, kNT, A>(23);  // shipped encode
-    for (int k : {0, 28}) { add_enc<64, 1, 4, kNT, A>(k); add_enc<128, 1, 2, kNT, A>(k / 2); add_enc<256, 1, 1, kNT, A>(k / 4); }
-    for (int k : {10, 11, 12}) { add_enc<128, 2, 1, kNT, A>(k); }
-    for (int k : {5, 6}) { add_enc<256, 2, 1, kNT, A>(k); add_enc<256, 1, 1, kNT, A>(k); }
+    for (int k : {22, 23, 24}) { add_map2<0>(k); add_map2<1>(k); }
+    add_enc<64, 2, 2, kNT, A>(23);
     uint64_t ref_d = 0, ref_e = checksum(d_packed, N / 32, s); bool have = false;
     for (auto& v : vs) {
         if (v.is_enc) {
