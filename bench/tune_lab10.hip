@@ -127,6 +127,24 @@ template <int MODE> void add_map2(int cap) {
     size_t lds = (size_t)(163840 / cap) / 256 * 256;
     vs.push_back({n, [t, lds](hipStream_t s) { hipLaunchKernelGGL((enc_map2<MODE>), dim3((unsigned)t), dim3(64), lds, s, d_in, d_packed, t); }, {}, true}); }
 
+
+// residency limited per SIMD through the occupancy attribute instead of per CU through dummy LDS
+template <int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void enc_wpe(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    const uint64_t t = tile_of_block<2>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * 2048, 2048);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * 512, 512);
+    const uint32_t tid = threadIdx.x;
+    u32x4 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * 64 + tid) * 16, 0, kNT));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_buffer_store_b32(enc16<false>(v[u]), rout, (u * 64 + tid) * 4, 0, kSC0 | kSC1 | kNT);
+}
+template <int WPE> void add_wpe() {
+    char n[96]; snprintf(n, 96, "enc waves_per_eu<=%d (no LDS cap)", WPE); uint64_t t = N / 2048;
+    vs.push_back({n, [t](hipStream_t s) { hipLaunchKernelGGL((enc_wpe<WPE>), dim3((unsigned)t), dim3(64), 0, s, d_in, d_packed, t); }, {}, true}); }
+
 static uint64_t checksum(const void* p, uint64_t words, hipStream_t s) {
     static unsigned long long* d_sum = nullptr;
     if (!d_sum) CK(hipMalloc(&d_sum, 8));
@@ -146,7 +164,7 @@ int main(int argc, char** argv) {
     constexpr int A = kSC0 | kSC1 | kNT;
     add<128, 2, 4, 0, 0, A>(13);  // shipped decode
     add_enc<64, 2, 2, kNT, A>(23);  // shipped encode
-    for (int k : {22, 23, 24}) { add_map2<0>(k); add_map2<1>(k); }
+    add_wpe<4>(); add_wpe<5>(); add_wpe<6>(); add_wpe<7>(); add_wpe<8>();
     add_enc<64, 2, 2, kNT, A>(23);
     uint64_t ref_d = 0, ref_e = checksum(d_packed, N / 32, s); bool have = false;
     for (auto& v : vs) {
