@@ -261,6 +261,19 @@ def main():
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
     enc_ms_max, dec_ms_max = float(km[0].item()), float(km[1].item())
 
+    # BASELINE.json configs[3] in passing: the FUSED round trip (cnt_round_trip_dev) over the same
+    # buffers, outside the timed region -- reported beside the headline, never part of `value`
+    fused_ms = None
+    if world == 1:
+        fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        cn.round_trip_dev(d_in, out_bits=d_packed, out_n=d_out)
+        fe[0].record()
+        for _ in range(3):
+            cn.round_trip_dev(d_in, out_bits=d_packed, out_n=d_out)
+        fe[1].record()
+        fe[1].synchronize()
+        fused_ms = fe[0].elapsed_time(fe[1]) / 3
+
     verified = None
     if not args.no_verify:
         # Outside the timed region, and WITHOUT the oracle (bench.py may touch oracle/ only in its
@@ -331,6 +344,14 @@ def main():
                                 "nt_per_gpu on every rank (nt_per_step = 2 x n_gpus x nt_per_gpu); equals the harmonic mean "
                                 "of the encode and decode rates",
         }
+        if fused_ms is not None:
+            fgbs = 2.25 * n_len / (fused_ms * 1e-3) / 1e9
+            line["fused_round_trip"] = {
+                "what": "cnt_round_trip_dev: one pass reads the ASCII and writes packed words + decoded ASCII "
+                        "(BASELINE.json configs[3]); measured after the timed region, not part of value",
+                "ms": round(fused_ms, 4), "nt_converted_gnts": round(2 * n_len / (fused_ms * 1e-3) / 1e9, 3),
+                "bytes_per_nt": 2.25, "achieved": round(fgbs, 1), "unit": "GB/s", "frac": round(fgbs / HBM_PEAK_GBS, 4),
+            }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "cnt_n_to_bits_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
     "cnt_bits_to_n_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
     "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
+    "cnt_round_trip_dev": (_int, [_vp, _sz, _vp, _sz, _vp, _uint, _vp]),
     "cnt_bits_to_n2_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
     "cnt_fill_random_acgt_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),
     "cnt_fill_random_acgtn_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),

@@ -216,6 +216,32 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
     __builtin_amdgcn_raw_buffer_store_b32(o1, rout, (kWave + lane) * 4, 0, SAUX);
 }
 
+// FUSED round trip (BASELINE.json configs[3]): one pass that reads the ASCII once and writes BOTH the
+// packed words and the decoded (canonical: upper case, U -> T) ASCII -- encode's tile shape, the
+// packed dword a lane just built is decoded from registers, so the packed form is never read back:
+// 1 + 0.25 + 1 = 2.25 B/nt instead of the 2.5 B/nt of encode followed by decode.
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed,
+                                                           uint8_t* __restrict__ back, uint64_t n_tiles) {
+    constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_PK = TILE_IN / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
+    const __amdgpu_buffer_rsrc_t rpk = rsrc_of(packed + t * TILE_PK, TILE_PK);
+    const __amdgpu_buffer_rsrc_t rbk = rsrc_of(back + t * TILE_IN, TILE_IN);
+    const uint32_t tid = threadIdx.x;
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + tid) * 16, 0, LAUX));
+    touch_residency_pad(n_tiles, v[0].x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t code = enc16<STRICT>(v[u]);
+        __builtin_amdgcn_raw_buffer_store_b32(code, rpk, (u * BLOCK + tid) * 4, 0, SAUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(code)), rbk, (u * BLOCK + tid) * 16, 0, SAUX);
+    }
+}
+
 // LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,
 // packs to U dwords per lane, parks them in its private LDS slab in output order
 // (ds_write_b32, conflict-free), reads back 16 B per lane (ds_read_b128) and

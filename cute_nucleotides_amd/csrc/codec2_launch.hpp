@@ -103,6 +103,20 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
     }
 }
 
+// Fused round trip: whole 2-KiB tiles only; all three pointers 128-B aligned.  `cap` = resident
+// one-wave workgroups per CU (0 = uncapped).
+constexpr uint32_t kRoundTripTile = 64 * 2 * 16;
+template <bool STRICT>
+void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(64);
+    const uint32_t lds = lds_for_cap(cap);
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+        const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+                           in + first * kRoundTripTile, packed + first * (kRoundTripTile / 4), back + first * kRoundTripTile, n_tiles);
+    }
+}
+
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 0: default

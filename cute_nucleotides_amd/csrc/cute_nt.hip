@@ -55,6 +55,7 @@ std::atomic<int> g_decode2_variant{0};
 // inputs up to this many nucleotides that would need a second (ragged-end) launch anyway go through
 // the generic kernel alone: one launch instead of two or three
 std::atomic<int> g_small_nt{1 << 17};
+std::atomic<int> g_round_trip_cap{13};  // resident one-wave workgroups per CU of the fused round-trip kernel
 
 inline unsigned generic_grid(uint64_t items) {
     uint64_t b = (items + kBlock - 1) / kBlock;
@@ -361,6 +362,36 @@ int decode_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsign
 // input phase goes to n_to_bits2_window.  Decode: the stores are the wide side and 27 is a unit
 // mod 128, so a head of k = 19 * (-address mod 128) mod 128 words (27 * 19 = 1 mod 128) puts the
 // remaining output on a 128-B line for ANY pointer; the packed side just moves by k words.
+// Fused encode + decode (BASELINE.json configs[3]): d_bits = n_to_bits(d_n), d_back = bits_to_n(d_bits,
+// n_len), with the ASCII read once and the packed words never read back.  The fused tiles need all
+// three pointers on 128-B lines; anything else (and the ragged end) goes through the two ordinary
+// entry points, same results.
+int round_trip_dev(const void* d_n, size_t n_len, void* d_bits, size_t out_words, void* d_back, unsigned flags, hipStream_t s) {
+    const size_t words = cnt_words_for(n_len);
+    if (out_words < words) return CNT_ECAP;
+    if (flags & ~CNT_STRICT_LUT) return CNT_EINVAL;
+    if (n_len == 0) return CNT_OK;
+    if (!d_n || !d_bits || !d_back || !aligned(d_bits, 8)) return CNT_EINVAL;
+    uint64_t done = 0;
+    if (aligned(d_n, 128) && aligned(d_bits, 128) && aligned(d_back, 128)) {
+        const uint64_t tiles = n_len / kRoundTripTile;
+        const uint32_t cap = (uint32_t)g_round_trip_cap.load(std::memory_order_relaxed);
+        if (flags & CNT_STRICT_LUT)
+            launch_round_trip<true>(static_cast<const uint8_t*>(d_n), static_cast<uint8_t*>(d_bits), static_cast<uint8_t*>(d_back), tiles, cap, s);
+        else
+            launch_round_trip<false>(static_cast<const uint8_t*>(d_n), static_cast<uint8_t*>(d_bits), static_cast<uint8_t*>(d_back), tiles, cap, s);
+        HIP_TRY(hipGetLastError());
+        done = tiles * kRoundTripTile;  // a multiple of 32: the rest starts on a word
+    }
+    if (done < n_len) {
+        const size_t rest = n_len - done, rest_words = cnt_words_for(rest);
+        uint64_t* bits_rest = static_cast<uint64_t*>(d_bits) + (done >> 5);
+        CNT_TRY(encode_dev(static_cast<const uint8_t*>(d_n) + done, rest, bits_rest, rest_words, flags, s));
+        CNT_TRY(decode_dev(bits_rest, rest_words, rest, static_cast<uint8_t*>(d_back) + done, 0, s));
+    }
+    return CNT_OK;
+}
+
 int encode2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, hipStream_t s) {
     const size_t words = cnt_words2_for(n_len);
     if (out_words < words) return CNT_ECAP;
@@ -772,6 +803,9 @@ int cnt_n_to_bits_dev(const void* d_n, size_t n_len, void* d_out, size_t out_wor
 int cnt_bits_to_n_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, void* stream) {
     return decode_dev(d_bits, words, len, d_out, flags, static_cast<hipStream_t>(stream));
 }
+int cnt_round_trip_dev(const void* d_n, size_t n_len, void* d_bits, size_t out_words, void* d_back, unsigned flags, void* stream) {
+    return round_trip_dev(d_n, n_len, d_bits, out_words, d_back, flags, static_cast<hipStream_t>(stream));
+}
 int cnt_n_to_bits2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, void* stream) {
     return encode2_dev(d_n, n_len, d_out, out_words, flags, static_cast<hipStream_t>(stream));
 }
@@ -835,6 +869,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "decode2")) {
         if (value < 0 || value >= kNumDecode2Variants) return CNT_EINVAL;
         g_decode2_variant.store(value);
+    } else if (!strcmp(key, "round_trip_cap")) {
+        if (value < 0 || value > 32) return CNT_EINVAL;
+        g_round_trip_cap.store(value);
     } else if (!strcmp(key, "small_nt")) {
         if (value < 0) return CNT_EINVAL;
         g_small_nt.store(value);
@@ -851,6 +888,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "encode2")) *value = g_encode2_variant.load();
     else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
     else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
+    else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;

@@ -121,6 +121,25 @@ def n_to_bits_dev(n, out=None, strict_lut=False):
     return out[:words]
 
 
+def round_trip_dev(n, out_bits=None, out_n=None, strict_lut=False):
+    """Fused device-resident encode + decode: returns (packed words, canonical ASCII) of `n` in one
+    pass over it (cnt_round_trip_dev)."""
+    torch = _dev_guard(n)
+    if n.dtype != torch.uint8:
+        raise TypeError("nucleotides must be a uint8 tensor")
+    words = lib().cnt_words_for(n.numel())
+    if out_bits is None:
+        out_bits = torch.empty(words, dtype=torch.int64, device=n.device)
+    if out_n is None:
+        out_n = torch.empty(n.numel(), dtype=torch.uint8, device=n.device)
+    if out_bits.dtype != torch.int64 or out_n.dtype != torch.uint8 or out_n.numel() < n.numel() or not (
+            out_bits.is_cuda and out_n.is_cuda and out_bits.is_contiguous() and out_n.is_contiguous()):
+        raise ValueError("out_bits: contiguous int64 CUDA tensor; out_n: contiguous uint8 CUDA tensor with >= len(n) elements")
+    check(lib().cnt_round_trip_dev(ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out_bits.data_ptr()), out_bits.numel(),
+                                   ctypes.c_void_p(out_n.data_ptr()), CNT_STRICT_LUT if strict_lut else 0, _stream_ptr()))
+    return out_bits[:words], out_n[: n.numel()]
+
+
 def bits_to_n_dev(bits, length, out=None):
     """Device-resident decode: int64 CUDA tensor of packed words -> uint8 CUDA tensor [length]."""
     torch = _dev_guard(bits)

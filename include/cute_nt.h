@@ -110,6 +110,13 @@ int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_
 int cnt_n_to_bits_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *stream);
 int cnt_bits_to_n_dev(const void *d_bits, size_t words, size_t len, void *d_out, unsigned flags, void *stream);
 int cnt_n_to_bits2_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *stream);
+/* Fused encode + decode in one pass (BASELINE.json configs[3]): d_bits = n_to_bits(d_n) and
+ * d_back = bits_to_n(d_bits, n_len) -- i.e. the canonical spelling of the input: upper case,
+ * U -> T, and with CNT_STRICT_LUT every byte outside the alphabet -> 'A' (n_to_bits.rs:8-21
+ * followed by :23-30) -- reading the ASCII once and never re-reading the packed words (2.25
+ * instead of 2.5 bytes of HBM traffic per nucleotide).  d_back holds n_len bytes.  Full speed needs
+ * all three pointers 128-byte aligned; otherwise the call is the two calls above in sequence. */
+int cnt_round_trip_dev(const void *d_n, size_t n_len, void *d_bits, size_t out_words, void *d_back, unsigned flags, void *stream);
 int cnt_bits_to_n2_dev(const void *d_bits, size_t words, size_t len, void *d_out, unsigned flags, void *stream);
 
 /* ---- packed-domain operations ----------------------------------- */

@@ -466,6 +466,53 @@ def test_device_tier_is_graph_capturable(cn, oracle, torch_cuda, tuning, small_n
         assert bytes(d_out.cpu().numpy()) == bytes(n).upper().replace(b"U", b"T")
 
 
+# ---- fused round trip (BASELINE.json configs[3]) ----------------------------------------------
+@pytest.mark.parametrize("strict", [False, True])
+def test_fused_round_trip_matches_two_calls(cn, oracle, torch_cuda, strict):
+    """cnt_round_trip_dev == n_to_bits followed by bits_to_n, for aligned (fused tiles) and misaligned
+    (fallback) pointers, ragged sizes, any bytes under CNT_STRICT_LUT; guard bytes around both outputs."""
+    torch = torch_cuda
+    rng = np.random.default_rng(41)
+    for n_len in (1, 31, 2047, 2048, 2049, 40000, 2048 * 37 + 5, (1 << 20) + 13):
+        n = rng.integers(0, 256, n_len, dtype=np.uint8) if strict else _rand_valid(n_len, n_len)
+        want_bits = oracle.n_to_bits_lut(n)
+        want_back = oracle.bits_to_n_lut(want_bits, n_len)
+        words = want_bits.size
+        for in_off, bits_off, back_off in ((0, 0, 0), (128, 16, 256), (1, 0, 0), (0, 1, 0), (0, 0, 3)):
+            ibuf = torch.zeros(n_len + 256, dtype=torch.uint8, device="cuda")
+            view = ibuf[in_off : in_off + n_len]
+            view.copy_(torch.from_numpy(n))
+            pbuf = torch.full((words + 64,), -1, dtype=torch.int64, device="cuda")
+            bbuf = torch.full((n_len + 512,), 0x2A, dtype=torch.uint8, device="cuda")
+            bits, back = cn.round_trip_dev(view, out_bits=pbuf[bits_off : bits_off + words], out_n=bbuf[back_off : back_off + n_len],
+                                           strict_lut=strict)
+            p, b = pbuf.cpu().numpy(), bbuf.cpu().numpy()
+            assert np.array_equal(p[bits_off : bits_off + words].view(np.uint64), want_bits), (n_len, in_off, bits_off, back_off)
+            assert np.array_equal(b[back_off : back_off + n_len], want_back), (n_len, in_off, bits_off, back_off)
+            assert (p[:bits_off] == -1).all() and (p[bits_off + words :] == -1).all()
+            assert (b[:back_off] == 0x2A).all() and (b[back_off + n_len :] == 0x2A).all()
+
+
+def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda):
+    """configs[3]: fused encode+decode over a 64 GiB buffer (144 GiB resident): the decoded copy equals
+    the input (random upper-case ACGT is its own canonical form) and the packed words carry the same
+    checksum as the plain encoder's."""
+    torch = torch_cuda
+    from cute_nucleotides_amd import devutil
+
+    free, _ = torch.cuda.mem_get_info()
+    log2 = 36 if free > 150 * 2**30 else 33
+    n_len = (1 << log2) + 2048 * 3 + 77
+    d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d, 36)
+    bits, back = cn.round_trip_dev(d)
+    assert devutil.count_mismatch(d, back) == 0
+    del back
+    ref = cn.n_to_bits_dev(d)
+    assert devutil.checksum_words(bits) == devutil.checksum_words(ref)
+    assert devutil.count_mismatch(bits.view(torch.uint8), ref.view(torch.uint8)) == 0
+
+
 # ---- boundary behaviour of the C ABI -------------------------------------------------------
 def test_output_pointer_only_8_byte_aligned(cn, oracle, torch_cuda):
     """u64 outputs need 8-B alignment; 16-B is only needed for the fast path."""
