@@ -17,7 +17,9 @@ from cute_nucleotides_amd import devutil, packed_ops as po  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--reduce-xi", type=int, default=1, help="XCD-interleaved pages for the reductions (tuning key reduce_xi)")
 a = ap.parse_args()
+devutil.set_tuning("reduce_xi", a.reduce_xi)
 n = 1 << a.log2_nt
 d = torch.empty(n, dtype=torch.uint8, device="cuda")
 devutil.fill_random_acgt(d, 1)

@@ -55,6 +55,7 @@ std::atomic<int> g_decode2_variant{0};
 // inputs up to this many nucleotides that would need a second (ragged-end) launch anyway go through
 // the generic kernel alone: one launch instead of two or three
 std::atomic<int> g_small_nt{1 << 17};
+std::atomic<int> g_reduce_xi{1};  // hamming / validate tiles take their pages XCD-interleaved (packed_ops_kernels.hpp)
 std::atomic<int> g_round_trip_cap{13};  // resident one-wave workgroups per CU of the fused round-trip kernel
 
 inline unsigned generic_grid(uint64_t items) {
@@ -872,6 +873,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_cap")) {
         if (value < 0 || value > 32) return CNT_EINVAL;
         g_round_trip_cap.store(value);
+    } else if (!strcmp(key, "reduce_xi")) {
+        if (value < 0 || value > 1) return CNT_EINVAL;
+        g_reduce_xi.store(value);
     } else if (!strcmp(key, "small_nt")) {
         if (value < 0) return CNT_EINVAL;
         g_small_nt.store(value);
@@ -888,6 +892,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "encode2")) *value = g_encode2_variant.load();
     else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
     else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
+    else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;

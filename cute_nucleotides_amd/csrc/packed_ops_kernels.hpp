@@ -48,6 +48,28 @@ __device__ __forceinline__ uint64_t block_sum_to(uint64_t v, unsigned long long*
     return 0;
 }
 
+// Where the 16-B vector v of workgroup b's tile lives.  Linear: tile b, vector v.  XCD-interleaved
+// (XI): groups of 8 workgroups (one per XCD, block b runs on XCD b % 8) share a super-tile of 8 tiles
+// and take its 4-KiB pages round-robin, so that at any time the eight XCDs read eight CONSECUTIVE
+// pages and each one whole pages -- the access pattern the codec kernels get from their small tiles
+// (codec2_kernels.hpp), here for 32-64 KiB reduction tiles.  Returns the byte offset from `base` and
+// sets `base_off` to the start of the descriptor window.
+template <uint32_t TILE, bool XI>
+__device__ __forceinline__ uint32_t vec_offset(uint64_t b, uint64_t n_tiles, uint32_t v, uint64_t& win_base, uint32_t& win_bytes) {
+    if constexpr (XI) {
+        const uint64_t g = b >> 3;
+        if (((g + 1) << 3) <= n_tiles) {
+            win_base = g * 8ull * TILE;
+            win_bytes = 8u * TILE;
+            const uint32_t x = (uint32_t)(b & 7), page = v >> 8, off = v & 255u;
+            return ((page * 8u + x) << 12) + (off << 4);
+        }
+    }
+    win_base = b * (uint64_t)TILE;
+    win_bytes = TILE;
+    return v << 4;
+}
+
 // Hamming distance over whole 16-B vectors (64 nt each); tile = kRedBlock*U vectors per workgroup.
 // block_sum_to's sibling: the workgroup's sum goes to partial[blockIdx.x], no atomic
 __device__ __forceinline__ void block_sum_store(uint64_t v, unsigned long long* partial) {
@@ -79,17 +101,20 @@ inline unsigned sum_partials_grid(uint64_t n) {
     return (unsigned)(g < 1 ? 1 : g > 128 ? 128 : g);
 }
 
-template <int U>
+template <int U, bool XI>
 __global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
                                                            uint64_t n_tiles, unsigned long long* __restrict__ partial) {
     constexpr uint32_t TILE = kRedBlock * U * 16;
-    const uint64_t t = blockIdx.x;
-    const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + t * TILE, TILE), rb = rsrc_of(b + t * TILE, TILE);
+    uint64_t wb;
+    uint32_t wn, off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) off[u] = vec_offset<TILE, XI>(blockIdx.x, n_tiles, u * kRedBlock + threadIdx.x, wb, wn);
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + wb, wn), rb = rsrc_of(b + wb, wn);
     u32x4 va[U], vb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        va[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (u * kRedBlock + threadIdx.x) * 16, 0, kNT));
-        vb[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (u * kRedBlock + threadIdx.x) * 16, 0, kNT));
+        va[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[u], 0, kNT));
+        vb[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[u], 0, kNT));
     }
     uint32_t c = 0;
 #pragma unroll
@@ -211,15 +236,18 @@ __device__ __forceinline__ uint32_t invalid_bytes32(uint32_t x) {
     return __builtin_popcount(nz);
 }
 
-template <int U, bool ALLOW_N>
+template <int U, bool ALLOW_N, bool XI>
 __global__ __launch_bounds__(kRedBlock) void validate_tiles(const uint8_t* __restrict__ n, uint64_t n_tiles,
                                                             unsigned long long* __restrict__ partial) {
     constexpr uint32_t TILE = kRedBlock * U * 16;
-    const uint64_t t = blockIdx.x;
-    const __amdgpu_buffer_rsrc_t rn = rsrc_of(n + t * TILE, TILE);
+    uint64_t wb;
+    uint32_t wn, off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) off[u] = vec_offset<TILE, XI>(blockIdx.x, n_tiles, u * kRedBlock + threadIdx.x, wb, wn);
+    const __amdgpu_buffer_rsrc_t rn = rsrc_of(n + wb, wn);
     u32x4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rn, (u * kRedBlock + threadIdx.x) * 16, 0, kNT));
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rn, off[u], 0, kNT));
     uint32_t c = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u)
