@@ -23,7 +23,10 @@
 //     follows by 1.3 %);
 //   * letting each XCD (block b runs on XCD b%8) take its READ stream in whole 4-KiB pieces --
 //     two 2-KiB ASCII tiles per turn for encode, four 4-KiB output tiles (= 4 KiB of packed
-//     words) per turn for decode -- is worth 1-3 %; other group sizes lose;
+//     words) per turn for decode -- is worth 1-3 %; other group sizes lose.  What the maps that
+//     win have in common: every XCD only ever reads pages of ONE residue class mod 8, and the
+//     eight XCDs read eight consecutive pages at a time (bench/tune_lab10.hip; the reductions in
+//     packed_ops_kernels.hpp get the same property from vec_offset);
 //   * capping residency at ~24 waves per CU (dummy LDS) is worth another 2-3 %.
 // Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
 // per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)
