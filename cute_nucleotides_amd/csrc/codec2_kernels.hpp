@@ -24,9 +24,10 @@
 //   * letting each XCD (block b runs on XCD b%8) take its READ stream in whole 4-KiB pieces --
 //     two 2-KiB ASCII tiles per turn for encode, four 4-KiB output tiles (= 4 KiB of packed
 //     words) per turn for decode -- is worth 1-3 %; other group sizes lose.  What the maps that
-//     win have in common: every XCD only ever reads pages of ONE residue class mod 8, and the
-//     eight XCDs read eight consecutive pages at a time (bench/tune_lab10.hip; the reductions in
-//     packed_ops_kernels.hpp get the same property from vec_offset);
+//     win have in common: the eight XCDs read eight CONSECUTIVE pages at a time, each XCD whole
+//     pages, always of the same residue class mod 8 (bench/tune_lab10.hip; the reductions in
+//     packed_ops_kernels.hpp get the same property from vec_offset).  Class affinity without the
+//     consecutive order loses (tried on the 5-letter encoder);
 //   * capping residency at ~24 waves per CU (dummy LDS) is worth another 2-3 %.
 // Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
 // per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)
