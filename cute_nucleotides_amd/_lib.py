@@ -31,6 +31,8 @@ SIGNATURES = {
     "cnt_bits_to_n2": (_int, [_vp, _sz, _sz, _vp]),
     "cnt_n_to_bits_sharded": (_int, [_vp, _sz, _vp, _sz, _int]),
     "cnt_bits_to_n_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
+    "cnt_n_to_bits2_sharded": (_int, [_vp, _sz, _vp, _sz, _int]),
+    "cnt_bits_to_n2_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
     "cnt_n_to_bits_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
     "cnt_bits_to_n_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
     "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),

@@ -797,6 +797,39 @@ int cnt_bits_to_n_sharded(const uint64_t* bits, size_t words, size_t len, uint8_
     });
 }
 
+// 5-letter codec over N GPUs: same scheme, shards are whole numbers of 128-word tiles (3456 nt)
+int cnt_n_to_bits2_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev) {
+    if (out_words < cnt_words2_for(n_len)) return CNT_ECAP;
+    if (n_len == 0) return CNT_OK;
+    if (!n || !out) return CNT_EINVAL;
+    CNT_TRY(resolve_ndev(ndev, &ndev));
+    const size_t gran = 3456 * 4;
+    size_t per = (n_len + ndev - 1) / ndev;
+    per = (per + gran - 1) / gran * gran;
+    g_shard_pool_used.store(true);
+    return ShardPool::get().run(ndev, [=](int k) -> int {
+        const size_t lo = std::min(n_len, per * k), hi = std::min(n_len, per * (k + 1));
+        if (lo >= hi) return CNT_OK;
+        return cnt_n_to_bits2(n + lo, hi - lo, out + lo / 27, cnt_words2_for(hi - lo));
+    });
+}
+
+int cnt_bits_to_n2_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
+    if (words > SIZE_MAX / 27 || len > words * 27) return CNT_ELEN;
+    if (len == 0) return CNT_OK;
+    if (!bits || !out) return CNT_EINVAL;
+    CNT_TRY(resolve_ndev(ndev, &ndev));
+    const size_t gran = 3456 * 4;
+    size_t per = (len + ndev - 1) / ndev;
+    per = (per + gran - 1) / gran * gran;
+    g_shard_pool_used.store(true);
+    return ShardPool::get().run(ndev, [=](int k) -> int {
+        const size_t lo = std::min(len, per * k), hi = std::min(len, per * (k + 1));
+        if (lo >= hi) return CNT_OK;
+        return cnt_bits_to_n2(bits + lo / 27, cnt_words2_for(hi - lo), hi - lo, out + lo);
+    });
+}
+
 // ---- device tier --------------------------------------------------------------------
 int cnt_n_to_bits_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, void* stream) {
     return encode_dev(d_n, n_len, d_out, out_words, flags, static_cast<hipStream_t>(stream));

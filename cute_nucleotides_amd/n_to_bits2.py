@@ -29,6 +29,23 @@ def bits_to_n2_hip(bits, length):
     return out
 
 
+def n_to_bits2_hip_sharded(n, ndev=0):
+    """n_to_bits2_hip with the buffer cut into contiguous chunks over `ndev` GPUs (0 = all)."""
+    n = _u8(n)
+    out = np.empty(lib().cnt_words2_for(n.size), dtype=np.uint64)
+    check(lib().cnt_n_to_bits2_sharded(_p(n), n.size, _p(out), out.size, ndev))
+    return out
+
+
+def bits_to_n2_hip_sharded(bits, length, ndev=0):
+    bits = _u64(bits)
+    if length > bits.size * 27:
+        check(_lib.CNT_ELEN)
+    out = np.empty(length, dtype=np.uint8)
+    check(lib().cnt_bits_to_n2_sharded(_p(bits), bits.size, length, _p(out), ndev))
+    return out
+
+
 def words2_for(n_len):
     return lib().cnt_words2_for(n_len)
 

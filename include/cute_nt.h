@@ -97,6 +97,9 @@ int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out)
  * device, outputs land in disjoint ranges of `out`. */
 int cnt_n_to_bits_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
 int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
+/* the 5-letter codec over ndev GPUs (shards are whole 128-word tiles = 3456 nt) */
+int cnt_n_to_bits2_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
+int cnt_bits_to_n2_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
 
 /* ---- device-pointer tier: what the roofline metric measures ------------------- */
 /* Pointers are device memory on the calling thread's current device.  `stream`

@@ -122,6 +122,19 @@ def test_decode_alignment_matrix(cn, oracle, no_small_path):
                 assert np.array_equal(got[128 + oo : 128 + oo + length], want_full[:length]), (wo, oo, length)
 
 
+def test_sharded_tier_single_device(cn, oracle):
+    from cute_nucleotides_amd import n_to_bits2 as n2
+
+    for n_len in (1, 3456 * 4 - 1, 3456 * 4, 3456 * 9 + 5, (1 << 21) + 7):
+        n = ALPHA[np.random.default_rng(n_len).integers(0, ALPHA.size, n_len)]
+        want = oracle.n_to_bits2_lut(n)
+        got = n2.n_to_bits2_hip_sharded(n, ndev=1)
+        assert np.array_equal(got, want)
+        assert np.array_equal(n2.bits_to_n2_hip_sharded(got, n_len, ndev=0), oracle.bits_to_n2_lut(want, n_len))
+    with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
+        n2.bits_to_n2_hip_sharded(got, got.size * 27 + 1)
+
+
 def test_arbitrary_words_and_bytes(cn, oracle):
     """Words no encoder produces (7-bit fields 125..127, bit 63 set) decode like the oracle
     defines; strict mode encodes non-alphabet bytes as 0 like BYTE_LUT (n_to_bits2.rs:8-23)."""
