@@ -22,6 +22,8 @@ extern "C" {
     fn cnt_bits_to_n2(bits: *const u64, words: usize, len: usize, out: *mut u8) -> c_int;
     fn cnt_n_to_bits_sharded(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, ndev: c_int) -> c_int;
     fn cnt_bits_to_n_sharded(bits: *const u64, words: usize, len: usize, out: *mut u8, ndev: c_int) -> c_int;
+    fn cnt_n_to_bits2_sharded(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, ndev: c_int) -> c_int;
+    fn cnt_bits_to_n2_sharded(bits: *const u64, words: usize, len: usize, out: *mut u8, ndev: c_int) -> c_int;
 }
 
 const CNT_STRICT_LUT: c_uint = 1;
@@ -112,6 +114,29 @@ pub fn bits_to_n_hip_sharded(bits: &[u64], len: usize, ndev: i32) -> Vec<u8> {
     let mut res: Vec<u8> = Vec::with_capacity(len);
     unsafe {
         check(cnt_bits_to_n_sharded(bits.as_ptr(), bits.len(), len, res.as_mut_ptr(), ndev));
+        res.set_len(len);
+    }
+    res
+}
+
+/// The 5-letter codec over `ndev` GPUs.
+pub fn n_to_bits2_hip_sharded(n: &[u8], ndev: i32) -> Vec<u64> {
+    let words = unsafe { cnt_words2_for(n.len()) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    unsafe {
+        check(cnt_n_to_bits2_sharded(n.as_ptr(), n.len(), res.as_mut_ptr(), words, ndev));
+        res.set_len(words);
+    }
+    res
+}
+
+pub fn bits_to_n2_hip_sharded(bits: &[u64], len: usize, ndev: i32) -> Vec<u8> {
+    if len > bits.len() * 27 {
+        panic!("The length is greater than the number of nucleotides!");
+    }
+    let mut res: Vec<u8> = Vec::with_capacity(len);
+    unsafe {
+        check(cnt_bits_to_n2_sharded(bits.as_ptr(), bits.len(), len, res.as_mut_ptr(), ndev));
         res.set_len(len);
     }
     res
