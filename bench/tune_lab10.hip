@@ -163,9 +163,10 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     constexpr int A = kSC0 | kSC1 | kNT;
     add<128, 2, 4, 0, 0, A>(13);  // shipped decode
-    add_enc<64, 2, 2, kNT, A>(23);  // shipped encode
-    add_wpe<4>(); add_wpe<5>(); add_wpe<6>(); add_wpe<7>(); add_wpe<8>();
-    add_enc<64, 2, 2, kNT, A>(23);
+    for (int k : {4, 5}) { add<512, 2, 1, 0, 0, A>(k); add<512, 2, 1, 1, 0, A>(k); }
+    for (int k : {2, 3}) { add<1024, 1, 1, 0, 0, A>(k); }
+    for (int k : {6, 7, 8}) { add<512, 1, 2, 0, 0, A>(k); }
+    add<128, 2, 4, 0, 0, A>(13);
     uint64_t ref_d = 0, ref_e = checksum(d_packed, N / 32, s); bool have = false;
     for (auto& v : vs) {
         if (v.is_enc) {
