@@ -33,6 +33,12 @@ SIGNATURES = {
     "cnt_bits_to_n_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
     "cnt_n_to_bits2_sharded": (_int, [_vp, _sz, _vp, _sz, _int]),
     "cnt_bits_to_n2_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
+    "cnt_shard_range": (_int, [_sz, _int, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "cnt_shard_worker_info": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "cnt_n_to_bits_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
+    "cnt_bits_to_n_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
+    "cnt_n_to_bits2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
+    "cnt_bits_to_n2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
     "cnt_n_to_bits_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
     "cnt_bits_to_n_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
     "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),

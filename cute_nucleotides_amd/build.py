@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcute_nt_hip.so")
 SOURCES = ["cute_nt.hip"]
-HEADERS = ["codec2_kernels.hpp", "codec2_launch.hpp", "codec5_kernels.hpp", "codec5_launch.hpp", "util_kernels.hpp", os.path.join("..", "..", "include", "cute_nt.h")]
+# every file the one translation unit includes: a non-forced build() must notice an edit to any of them
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))) + [os.path.join("..", "..", "include", "cute_nt.h")]
 ARCH = "gfx950"
 
 

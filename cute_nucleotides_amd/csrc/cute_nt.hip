@@ -25,6 +25,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "codec2_kernels.hpp"
 #include "codec2_launch.hpp"
 #include "codec5_kernels.hpp"
@@ -95,6 +98,14 @@ class CopyPool {
         std::unique_lock<std::mutex> lk(m_);
         cv_done_.wait(lk, [&] { return pending_ == 0; });
     }
+    // Sharded tier: worker pools are sized so that the TOTAL over all devices stays bounded
+    // (0 = back to CNT_HOST_COPY_THREADS).  Takes effect at the next copy().
+    void set_limit(int n) {
+        if (n == limit_) return;
+        limit_ = n;
+        if (started_) stop();
+    }
+    int size() const { return started_ ? n_threads_ : 0; }
     void stop() {
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -118,6 +129,7 @@ class CopyPool {
             started_ = true;
             int t = 4;
             if (const char* e = getenv("CNT_HOST_COPY_THREADS")) t = atoi(e);
+            if (limit_ > 0) t = std::min(t, limit_);
             n_threads_ = std::max(1, std::min(t, 16));
             for (int k = 1; k < n_threads_; ++k) workers_.emplace_back([this] { run(); });
         }
@@ -141,7 +153,7 @@ class CopyPool {
     std::vector<Job> jobs_;
     std::vector<std::thread> workers_;
     size_t pending_ = 0;
-    int n_threads_ = 1;
+    int n_threads_ = 1, limit_ = 0;
     bool stop_ = false, started_ = false;
 };
 
@@ -156,10 +168,20 @@ struct DevCtx {
     void* hd_in = nullptr;   // h_in[0] / h_out[0] as the device sees them (zero-copy path for small inputs)
     void* hd_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};  // device-resident sharded tier: per-shard kernel time
 
-    int ensure(size_t need_in, size_t need_out) {
+    int ensure_streams() {
         for (int i = 0; i < 2; ++i)
             if (!stream[i]) HIP_TRY(hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking));
+        return CNT_OK;
+    }
+    int ensure_events() {
+        for (int i = 0; i < 2; ++i)
+            if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+        return CNT_OK;
+    }
+    int ensure(size_t need_in, size_t need_out) {
+        CNT_TRY(ensure_streams());
         if (need_in > cap_in) {
             cap_in = 0;  // a failure below must not leave a stale capacity behind
             for (int i = 0; i < 2; ++i) {
@@ -195,6 +217,8 @@ struct DevCtx {
         if (hipSetDevice(device) == hipSuccess) {
             for (int i = 0; i < 2; ++i) {
                 if (stream[i]) (void)hipStreamDestroy(stream[i]);
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+                ev[i] = nullptr;
                 if (d_in[i]) (void)hipFree(d_in[i]);
                 if (d_out[i]) (void)hipFree(d_out[i]);
                 if (h_in[i]) (void)hipHostFree(h_in[i]);
@@ -609,33 +633,127 @@ int host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, si
     return rc;
 }
 
-// ---- sharded tier: one persistent worker thread per device ---------------------------------
+// ---- sharded tier: one persistent worker thread per shard ------------------------------------
 // A worker keeps its device binding and its thread-local context (streams, pinned staging, device
 // scratch) between calls; spawning threads per call would re-create 2 x 32 MiB of pinned memory per
 // device every time.  The pool is created on first use and deliberately never destroyed: its
 // threads sleep on a condition variable until the process exits, so no HIP call can run from a
 // static destructor after the runtime is gone.  cnt_shutdown() asks the workers to release their
 // contexts.  One sharded call runs at a time (callers queue on call_m_).
+//
+// Placement on a real node (8 GPUs behind two sockets): the staging copies of a shard are plain
+// memcpy between the caller's pages and pinned memory, so the worker -- and the copy-pool threads
+// it spawns, which inherit its mask -- is pinned to the CPUs of the NUMA node its GPU hangs off
+// (/sys/bus/pci/devices/<bdf>/numa_node, intersected with the mask the process was given;
+// CNT_SHARD_NUMA=0 switches it off).  The copy pools are sized so that their TOTAL over all
+// devices stays at CNT_SHARD_COPY_THREADS_TOTAL (default 32): 8 GPUs -> 4 threads each, 16 shards
+// -> 2 each.
+//
+// Test hook (never set in production): CNT_SHARD_ALIAS_DEVICES=1 lets ndev exceed the number of
+// visible devices (up to kMaxShards) and binds worker k to device k % count, so the partition
+// arithmetic, the empty-shard and the ragged-last-shard paths run with ndev > 1 on a 1-GPU box.
+constexpr int kMaxShards = 64;
+
+bool shard_alias() {
+    const char* e = getenv("CNT_SHARD_ALIAS_DEVICES");
+    return e && e[0] == '1';
+}
+
+// CPUs of the NUMA node a device sits on (empty set = unknown / not pinning)
+struct NumaInfo {
+    int node = -1;
+    int n_cpus = 0;
+    cpu_set_t cpus;
+    char bdf[32] = {0};
+};
+
+bool parse_cpulist(const char* text, cpu_set_t* out) {  // "0-63,128-191"
+    CPU_ZERO(out);
+    const char* p = text;
+    bool any = false;
+    while (*p) {
+        char* end = nullptr;
+        long lo = strtol(p, &end, 10);
+        if (end == p) break;
+        long hi = lo;
+        p = end;
+        if (*p == '-') {
+            hi = strtol(p + 1, &end, 10);
+            if (end == p + 1) break;
+            p = end;
+        }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) {
+            if (c >= 0) {
+                CPU_SET((int)c, out);
+                any = true;
+            }
+        }
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    }
+    return any;
+}
+
+bool read_small_file(const char* path, char* buf, size_t cap) {
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    const size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+
+NumaInfo numa_of_device(int device, const cpu_set_t& allowed) {
+    NumaInfo info;
+    CPU_ZERO(&info.cpus);
+    if (hipDeviceGetPCIBusId(info.bdf, (int)sizeof info.bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        info.bdf[0] = 0;
+        return info;
+    }
+    for (char* c = info.bdf; *c; ++c)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // sysfs spells the address in lower case
+    char path[160], buf[4096];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", info.bdf);
+    if (!read_small_file(path, buf, sizeof buf)) return info;
+    const int node = atoi(buf);
+    if (node < 0) return info;  // -1: the platform does not say
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    cpu_set_t node_cpus;
+    if (!read_small_file(path, buf, sizeof buf) || !parse_cpulist(buf, &node_cpus)) return info;
+    CPU_AND(&info.cpus, &node_cpus, &allowed);
+    info.n_cpus = CPU_COUNT(&info.cpus);
+    info.node = node;
+    return info;
+}
+
 class ShardPool {
    public:
     static ShardPool& get() {
         static ShardPool* p = new ShardPool;  // leaked on purpose, see above
         return *p;
     }
-    // fn(k) runs on the worker bound to device k, k in [0, ndev); returns the first non-OK status
-    int run(int ndev, const std::function<int(int)>& fn) {
+    // fn(k) runs on worker k, bound to device k % count, k in [0, nshards); returns the first non-OK status
+    int run(int nshards, int count, const std::function<int(int)>& fn) {
         std::lock_guard<std::mutex> one_call(call_m_);
         std::unique_lock<std::mutex> lk(m_);
-        while ((int)workers_.size() < ndev) {
+        if (workers_.empty()) (void)sched_getaffinity(0, sizeof allowed_, &allowed_);  // the mask the process was given
+        while ((int)workers_.size() < nshards) {
             const int k = (int)workers_.size();
             workers_.push_back(new Worker);
             std::thread([this, k] { loop(k); }).detach();
         }
-        for (int k = 0; k < ndev; ++k) workers_[k]->job = &fn;
-        pending_ = ndev;
+        int total = 32;
+        if (const char* e = getenv("CNT_SHARD_COPY_THREADS_TOTAL")) total = atoi(e);
+        const int per_worker = std::max(1, total / std::max(1, nshards));
+        for (int k = 0; k < nshards; ++k) {
+            workers_[k]->job = &fn;
+            workers_[k]->want_device = k % count;
+            workers_[k]->copy_limit = per_worker;
+        }
+        pending_ = nshards;
         cv_work_.notify_all();
         cv_done_.wait(lk, [&] { return pending_ == 0; });
-        for (int k = 0; k < ndev; ++k)
+        for (int k = 0; k < nshards; ++k)
             if (workers_[k]->rc != CNT_OK) return workers_[k]->rc;
         return CNT_OK;
     }
@@ -643,41 +761,185 @@ class ShardPool {
         std::lock_guard<std::mutex> lk(m_);
         return (int)workers_.size();
     }
+    // what worker k is bound to (after its first job): device, NUMA node (-1 unknown), CPUs it may run
+    // on, copy-pool threads (0 = its pool has not copied anything big yet)
+    int info(int k, int* device, int* node, int* n_cpus, int* copy_threads) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (k < 0 || k >= (int)workers_.size()) return CNT_EINVAL;
+        const Worker& w = *workers_[k];
+        if (device) *device = w.device;
+        if (node) *node = w.numa.node;
+        if (n_cpus) *n_cpus = w.pinned ? w.numa.n_cpus : 0;
+        if (copy_threads) *copy_threads = w.copy_threads;
+        return CNT_OK;
+    }
 
    private:
     struct Worker {
         const std::function<int(int)>* job = nullptr;
         int rc = CNT_OK;
+        int want_device = 0, copy_limit = 0;
+        int device = -1, copy_threads = 0;
+        bool pinned = false;
+        NumaInfo numa;
     };
     void loop(int k) {
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             cv_work_.wait(lk, [&] { return workers_[k]->job != nullptr; });
-            const std::function<int(int)>* job = workers_[k]->job;
+            Worker& w = *workers_[k];
+            const std::function<int(int)>* job = w.job;
+            const int dev = w.want_device, limit = w.copy_limit;
+            const bool rebind = dev != w.device;
+            const cpu_set_t allowed = allowed_;
             lk.unlock();
-            int rc = hip_rc(hipSetDevice(k));
+            int rc = hip_rc(hipSetDevice(dev));
+            const bool bound = rc == CNT_OK;
+            NumaInfo numa;
+            bool pinned = false;
+            if (bound && rebind) {
+                const char* e = getenv("CNT_SHARD_NUMA");
+                numa = numa_of_device(dev, allowed);
+                if (!(e && e[0] == '0') && numa.n_cpus > 0)
+                    pinned = pthread_setaffinity_np(pthread_self(), sizeof numa.cpus, &numa.cpus) == 0;
+                else
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof allowed, &allowed);
+                t_ctx.pool.stop();  // its threads carry the old mask; they restart under the new one
+            }
+            t_ctx.pool.set_limit(limit);
             if (rc == CNT_OK) rc = (*job)(k);
+            const int copy_threads = t_ctx.pool.size();
             lk.lock();
-            workers_[k]->rc = rc;
-            workers_[k]->job = nullptr;
+            if (bound && rebind) {
+                w.device = dev;
+                w.numa = numa;
+                w.pinned = pinned;
+            }
+            w.copy_threads = copy_threads;
+            w.rc = rc;
+            w.job = nullptr;
             if (--pending_ == 0) cv_done_.notify_all();
         }
     }
     std::mutex call_m_, m_;
     std::condition_variable cv_work_, cv_done_;
     std::vector<Worker*> workers_;
+    cpu_set_t allowed_;
     int pending_ = 0;
 };
 std::atomic<bool> g_shard_pool_used{false};
 
-int resolve_ndev(int ndev, int* out) {
+// ndev <= 0: all visible devices.  *count = visible devices (worker k -> device k % count).
+int resolve_ndev(int ndev, int* out, int* count_out) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return CNT_ENODEV;
     if (ndev <= 0) ndev = count;
-    if (ndev > count) return CNT_ENODEV;
+    if (ndev > count && !(shard_alias() && ndev <= kMaxShards)) return CNT_ENODEV;
     *out = ndev;
+    *count_out = count;
     return CNT_OK;
+}
+
+// The partition: shard k of `ndev` gets nt [k*C, min(N, (k+1)*C)), C = ceil(N/ndev)
+// rounded up to a whole number of kernel tiles -- 16384 nt for the 2-bit codec (a multiple of 32),
+// 4 x 3456 nt for the 5-letter codec (a multiple of 27) -- so every shard starts on a word (and tile)
+// boundary and only the last non-empty shard has a tail; shards past the end are empty (lo == hi == N).
+inline size_t shard_gran(int unit_nt) { return unit_nt == 27 ? (size_t)3456 * 4 : (size_t)16384; }
+inline void shard_range(size_t n_len, int ndev, int k, int unit_nt, size_t* lo, size_t* hi) {
+    const size_t gran = shard_gran(unit_nt);
+    size_t per = n_len / ndev + (n_len % ndev ? 1 : 0);
+    per = per > SIZE_MAX - gran ? SIZE_MAX : (per / gran + (per % gran ? 1 : 0)) * gran;  // saturate, never wrap
+    // k * per cannot overflow for any n_len that exists in memory, but saturate anyway
+    const size_t a = (per && (size_t)k > SIZE_MAX / per) ? n_len : std::min(n_len, per * (size_t)k);
+    const size_t b = (per && (size_t)(k + 1) > SIZE_MAX / per) ? n_len : std::min(n_len, per * (size_t)(k + 1));
+    *lo = a;
+    *hi = b;
+}
+
+int sharded_host_encode(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev, int unit_nt,
+                        int (*fn)(const uint8_t*, size_t, uint64_t*, size_t)) {
+    const size_t words = (n_len + unit_nt - 1) / unit_nt;
+    if (out_words < words) return CNT_ECAP;
+    if (n_len == 0) return CNT_OK;
+    if (!n || !out) return CNT_EINVAL;
+    int count = 0;
+    CNT_TRY(resolve_ndev(ndev, &ndev, &count));
+    g_shard_pool_used.store(true);
+    return ShardPool::get().run(ndev, count, [=](int k) -> int {
+        size_t lo, hi;
+        shard_range(n_len, ndev, k, unit_nt, &lo, &hi);
+        if (lo >= hi) return CNT_OK;
+        return fn(n + lo, hi - lo, out + lo / unit_nt, (hi - lo + unit_nt - 1) / unit_nt);
+    });
+}
+
+int sharded_host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev, int unit_nt,
+                        int (*fn)(const uint64_t*, size_t, size_t, uint8_t*)) {
+    if (words > SIZE_MAX / unit_nt || len > words * unit_nt) return CNT_ELEN;
+    if (len == 0) return CNT_OK;
+    if (!bits || !out) return CNT_EINVAL;
+    int count = 0;
+    CNT_TRY(resolve_ndev(ndev, &ndev, &count));
+    g_shard_pool_used.store(true);
+    return ShardPool::get().run(ndev, count, [=](int k) -> int {
+        size_t lo, hi;
+        shard_range(len, ndev, k, unit_nt, &lo, &hi);
+        if (lo >= hi) return CNT_OK;
+        return fn(bits + lo / unit_nt, (hi - lo + unit_nt - 1) / unit_nt, hi - lo, out + lo);
+    });
+}
+
+// Device-resident sharded tier: shard k already lives on device k % count; the calling thread
+// enqueues every shard on that device's own stream (enqueue is asynchronous, so the devices run
+// concurrently without helper threads), then waits for all of them.  No host staging, no collective.
+template <typename Enqueue>
+int sharded_dev_run(int ndev, float* shard_ms, Enqueue&& enqueue) {
+    int count = 0;
+    CNT_TRY(resolve_ndev(ndev, &ndev, &count));
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    int rc = CNT_OK;
+    std::vector<DevCtx*> ctx((size_t)ndev, nullptr);
+    std::vector<int> slot((size_t)ndev, 0);
+    for (int k = 0; k < ndev && rc == CNT_OK; ++k) {
+        rc = hip_rc(hipSetDevice(k % count));
+        if (rc == CNT_OK) rc = t_ctx.get(&ctx[k]);
+        if (rc == CNT_OK) rc = ctx[k]->ensure_streams();
+        if (rc != CNT_OK) {
+            ctx[k] = nullptr;
+            break;
+        }
+        // aliased shards (test hook) share a device: they alternate between its two streams; timing needs
+        // the device's single event pair to itself, so with events the aliased shards run one after the other
+        slot[k] = (k / count) & 1;
+        hipStream_t s = ctx[k]->stream[slot[k]];
+        if (shard_ms) {
+            rc = ctx[k]->ensure_events();
+            if (rc == CNT_OK && k >= count) rc = hip_rc(hipStreamSynchronize(ctx[k - count]->stream[slot[k - count]]));
+            if (rc == CNT_OK && k >= count) {
+                float ms = 0.f;
+                rc = hip_rc(hipEventElapsedTime(&ms, ctx[k]->ev[0], ctx[k]->ev[1]));
+                shard_ms[k - count] = ms;
+            }
+            if (rc == CNT_OK) rc = hip_rc(hipEventRecord(ctx[k]->ev[0], s));
+        }
+        if (rc == CNT_OK) rc = enqueue(k, s);
+        if (rc == CNT_OK && shard_ms) rc = hip_rc(hipEventRecord(ctx[k]->ev[1], s));
+    }
+    for (int k = 0; k < ndev; ++k) {  // wait for everything that was enqueued, also after an error
+        if (!ctx[k]) continue;
+        int r2 = hip_rc(hipSetDevice(k % count));
+        if (r2 == CNT_OK) r2 = hip_rc(hipStreamSynchronize(ctx[k]->stream[slot[k]]));
+        if (r2 == CNT_OK && shard_ms && rc == CNT_OK && k + count >= ndev) {
+            float ms = 0.f;
+            r2 = hip_rc(hipEventElapsedTime(&ms, ctx[k]->ev[0], ctx[k]->ev[1]));
+            shard_ms[k] = ms;
+        }
+        if (rc == CNT_OK) rc = r2;
+    }
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 }  // namespace
@@ -739,7 +1001,9 @@ int cnt_shutdown(void) {
     if (g_shard_pool_used.load()) {  // the sharded tier's workers hold contexts of their own
         ShardPool& pool = ShardPool::get();
         const int n = pool.size();
-        if (n > 0) return pool.run(n, [](int) -> int { return release_thread_ctx(); });
+        int count = 0;
+        if (n > 0 && hipGetDeviceCount(&count) == hipSuccess && count > 0)
+            return pool.run(n, count, [](int) -> int { return release_thread_ctx(); });
     }
     return CNT_OK;
 }
@@ -762,72 +1026,58 @@ int cnt_bits_to_n2(const uint64_t* bits, size_t words, size_t len, uint8_t* out)
 }
 
 // ---- sharded tier -------------------------------------------------------------------
-// GPU k of G gets nt [k*C, min(N,(k+1)*C)), C = ceil(N/G) rounded up to a whole
-// number of 16 KiB tiles, so every shard starts on a word (and tile) boundary and
-// only the last shard has a tail.  No collective: outputs are disjoint ranges.
+// Partition: shard_range() above.  No collective: outputs are disjoint ranges of `out`.
 int cnt_n_to_bits_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev) {
-    if (out_words < cnt_words_for(n_len)) return CNT_ECAP;
-    if (n_len == 0) return CNT_OK;
-    if (!n || !out) return CNT_EINVAL;
-    CNT_TRY(resolve_ndev(ndev, &ndev));
-    const size_t gran = 16384;
-    size_t per = (n_len + ndev - 1) / ndev;
-    per = (per + gran - 1) / gran * gran;
-    g_shard_pool_used.store(true);
-    return ShardPool::get().run(ndev, [=](int k) -> int {
-        const size_t lo = std::min(n_len, per * k), hi = std::min(n_len, per * (k + 1));
-        if (lo >= hi) return CNT_OK;
-        return cnt_n_to_bits(n + lo, hi - lo, out + (lo >> 5), cnt_words_for(hi - lo));
-    });
+    return sharded_host_encode(n, n_len, out, out_words, ndev, 32, cnt_n_to_bits);
 }
-
 int cnt_bits_to_n_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
-    if (len > (words << 5)) return CNT_ELEN;
-    if (len == 0) return CNT_OK;
-    if (!bits || !out) return CNT_EINVAL;
-    CNT_TRY(resolve_ndev(ndev, &ndev));
-    const size_t gran = 16384;
-    size_t per = (len + ndev - 1) / ndev;
-    per = (per + gran - 1) / gran * gran;
-    g_shard_pool_used.store(true);
-    return ShardPool::get().run(ndev, [=](int k) -> int {
-        const size_t lo = std::min(len, per * k), hi = std::min(len, per * (k + 1));
-        if (lo >= hi) return CNT_OK;
-        return cnt_bits_to_n(bits + (lo >> 5), cnt_words_for(hi - lo), hi - lo, out + lo);
-    });
+    return sharded_host_decode(bits, words, len, out, ndev, 32, cnt_bits_to_n);
 }
-
 // 5-letter codec over N GPUs: same scheme, shards are whole numbers of 128-word tiles (3456 nt)
 int cnt_n_to_bits2_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev) {
-    if (out_words < cnt_words2_for(n_len)) return CNT_ECAP;
-    if (n_len == 0) return CNT_OK;
-    if (!n || !out) return CNT_EINVAL;
-    CNT_TRY(resolve_ndev(ndev, &ndev));
-    const size_t gran = 3456 * 4;
-    size_t per = (n_len + ndev - 1) / ndev;
-    per = (per + gran - 1) / gran * gran;
-    g_shard_pool_used.store(true);
-    return ShardPool::get().run(ndev, [=](int k) -> int {
-        const size_t lo = std::min(n_len, per * k), hi = std::min(n_len, per * (k + 1));
-        if (lo >= hi) return CNT_OK;
-        return cnt_n_to_bits2(n + lo, hi - lo, out + lo / 27, cnt_words2_for(hi - lo));
-    });
+    return sharded_host_encode(n, n_len, out, out_words, ndev, 27, cnt_n_to_bits2);
+}
+int cnt_bits_to_n2_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
+    return sharded_host_decode(bits, words, len, out, ndev, 27, cnt_bits_to_n2);
 }
 
-int cnt_bits_to_n2_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
-    if (words > SIZE_MAX / 27 || len > words * 27) return CNT_ELEN;
-    if (len == 0) return CNT_OK;
-    if (!bits || !out) return CNT_EINVAL;
-    CNT_TRY(resolve_ndev(ndev, &ndev));
-    const size_t gran = 3456 * 4;
-    size_t per = (len + ndev - 1) / ndev;
-    per = (per + gran - 1) / gran * gran;
-    g_shard_pool_used.store(true);
-    return ShardPool::get().run(ndev, [=](int k) -> int {
-        const size_t lo = std::min(len, per * k), hi = std::min(len, per * (k + 1));
-        if (lo >= hi) return CNT_OK;
-        return cnt_bits_to_n2(bits + lo / 27, cnt_words2_for(hi - lo), hi - lo, out + lo);
-    });
+int cnt_shard_range(size_t n_len, int ndev, int k, int nt_per_word, size_t* lo, size_t* hi) {
+    if (!lo || !hi || ndev <= 0 || k < 0 || k >= ndev || (nt_per_word != 32 && nt_per_word != 27)) return CNT_EINVAL;
+    shard_range(n_len, ndev, k, nt_per_word, lo, hi);
+    return CNT_OK;
+}
+
+int cnt_shard_worker_info(int k, int* device, int* numa_node, int* n_cpus, int* copy_threads) {
+    if (!g_shard_pool_used.load()) return CNT_EINVAL;
+    return ShardPool::get().info(k, device, numa_node, n_cpus, copy_threads);
+}
+
+// device-resident shards: one entry per shard, shard k on device k (k % count under the test hook)
+static int sharded_dev_encode(const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, int ndev,
+                              unsigned flags, float* shard_ms, enc_fn fn) {
+    if (!d_n || !n_len || !d_out || !out_words) return CNT_EINVAL;
+    return sharded_dev_run(ndev, shard_ms, [&](int k, hipStream_t s) { return fn(d_n[k], n_len[k], d_out[k], out_words[k], flags, s); });
+}
+static int sharded_dev_decode(const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, int ndev,
+                              unsigned flags, float* shard_ms, dec_fn fn) {
+    if (!d_bits || !words || !len || !d_out) return CNT_EINVAL;
+    return sharded_dev_run(ndev, shard_ms, [&](int k, hipStream_t s) { return fn(d_bits[k], words[k], len[k], d_out[k], flags, s); });
+}
+int cnt_n_to_bits_sharded_dev(const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, int ndev,
+                              unsigned flags, float* shard_ms) {
+    return sharded_dev_encode(d_n, n_len, d_out, out_words, ndev, flags, shard_ms, encode_dev);
+}
+int cnt_bits_to_n_sharded_dev(const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, int ndev,
+                              unsigned flags, float* shard_ms) {
+    return sharded_dev_decode(d_bits, words, len, d_out, ndev, flags, shard_ms, decode_dev);
+}
+int cnt_n_to_bits2_sharded_dev(const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, int ndev,
+                               unsigned flags, float* shard_ms) {
+    return sharded_dev_encode(d_n, n_len, d_out, out_words, ndev, flags, shard_ms, encode2_dev);
+}
+int cnt_bits_to_n2_sharded_dev(const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, int ndev,
+                               unsigned flags, float* shard_ms) {
+    return sharded_dev_decode(d_bits, words, len, d_out, ndev, flags, shard_ms, decode2_dev);
 }
 
 // ---- device tier --------------------------------------------------------------------

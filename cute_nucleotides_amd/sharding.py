@@ -29,3 +29,102 @@ def word_range(lo, hi):
     if lo % 32:
         raise ValueError("shard must start on a word boundary")
     return lo // 32, (hi + 31) // 32
+
+SHARD_GRAN5_NT = 4 * 3456  # 5-letter codec: four 128-word tiles; multiple of 27
+
+
+def shard_range_c(n_len, ndev, k, nt_per_word=32):
+    """The C library's own copy of the partition (cnt_shard_range): what cnt_*_sharded use."""
+    import ctypes
+
+    from ._lib import check, lib
+
+    lo, hi = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    check(lib().cnt_shard_range(n_len, ndev, k, nt_per_word, ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
+
+
+def worker_info(k):
+    """{device, numa_node, n_cpus, copy_threads} of sharded-tier worker k (cnt_shard_worker_info)."""
+    import ctypes
+
+    from ._lib import check, lib
+
+    v = [ctypes.c_int(-1) for _ in range(4)]
+    check(lib().cnt_shard_worker_info(k, *[ctypes.byref(x) for x in v]))
+    return dict(zip(("device", "numa_node", "n_cpus", "copy_threads"), (x.value for x in v)))
+
+
+def _ptr_array(values):
+    import ctypes
+
+    return (ctypes.c_void_p * len(values))(*values)
+
+
+def _size_array(values):
+    import ctypes
+
+    return (ctypes.c_size_t * len(values))(*values)
+
+
+def n_to_bits_sharded_dev(shards, outs=None, five_letter=False, strict_lut=False, want_ms=False):
+    """Device-resident sharded encode (cnt_n_to_bits[2]_sharded_dev): `shards[k]` is a uint8 CUDA
+    tensor on device k (any device under CNT_SHARD_ALIAS_DEVICES=1); returns the list of int64
+    word tensors (and the per-shard device milliseconds when want_ms).  Synchronous."""
+    import ctypes
+
+    import torch
+
+    from ._lib import CNT_STRICT_LUT, check, lib
+
+    L = lib()
+    words_for = L.cnt_words2_for if five_letter else L.cnt_words_for
+    words = [words_for(t.numel()) for t in shards]
+    for t in shards:
+        if not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+            raise ValueError("shards must be contiguous uint8 CUDA tensors")
+    if outs is None:
+        outs = [torch.empty(w, dtype=torch.int64, device=t.device) for w, t in zip(words, shards)]
+    for o, w, t in zip(outs, words, shards):
+        if o.dtype != torch.int64 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < w:
+            raise ValueError("outs[k] must be a contiguous int64 CUDA tensor on shard k's device with >= words elements")
+    for t in shards:  # the library enqueues on its own streams: everything queued on torch's must be done
+        torch.cuda.synchronize(t.device)
+    ms = (ctypes.c_float * len(shards))() if want_ms else None
+    fn = L.cnt_n_to_bits2_sharded_dev if five_letter else L.cnt_n_to_bits_sharded_dev
+    check(fn(_ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+             _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), _size_array([o.numel() for o in outs]),
+             len(shards), CNT_STRICT_LUT if strict_lut else 0, ms))
+    outs = [o[:w] for o, w in zip(outs, words)]
+    return (outs, list(ms)) if want_ms else outs
+
+
+def bits_to_n_sharded_dev(shards, lengths, outs=None, five_letter=False, want_ms=False):
+    """Device-resident sharded decode: `shards[k]` int64 words on device k, `lengths[k]` nucleotides."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    from ._lib import check, lib
+
+    L = lib()
+    unit = 27 if five_letter else 32
+    for t, n in zip(shards, lengths):
+        if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("shards must be contiguous int64 CUDA tensors")
+        if n > t.numel() * unit:
+            check(_lib.CNT_ELEN)
+    if outs is None:
+        outs = [torch.empty(n, dtype=torch.uint8, device=t.device) for n, t in zip(lengths, shards)]
+    for o, n, t in zip(outs, lengths, shards):
+        if o.dtype != torch.uint8 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < n:
+            raise ValueError("outs[k] must be a contiguous uint8 CUDA tensor on shard k's device with >= length elements")
+    for t in shards:
+        torch.cuda.synchronize(t.device)
+    ms = (ctypes.c_float * len(shards))() if want_ms else None
+    fn = L.cnt_bits_to_n2_sharded_dev if five_letter else L.cnt_bits_to_n_sharded_dev
+    check(fn(_ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+             _size_array(list(lengths)), _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), len(shards), 0, ms))
+    outs = [o[:n] for o, n in zip(outs, lengths)]
+    return (outs, list(ms)) if want_ms else outs

@@ -93,13 +93,48 @@ int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out)
 
 /* ---- multi-GPU host tier: contiguous-chunk sharding, no collective ------------ */
 /* Same contracts as above; the buffer is cut into `ndev` contiguous chunks on
- * word boundaries (ndev <= 0: all visible devices), one host thread + stream per
- * device, outputs land in disjoint ranges of `out`. */
+ * word boundaries (ndev <= 0: all visible devices), one persistent host thread +
+ * streams per shard, outputs land in disjoint ranges of `out` (the reference's
+ * word independence, n_to_bits.rs:38-43: word w depends on nt [32w, 32w+32) only).
+ * Each worker (and the copy threads it owns) is pinned to the CPUs of its GPU's
+ * NUMA node; CNT_SHARD_NUMA=0 disables that, CNT_SHARD_COPY_THREADS_TOTAL
+ * (default 32) bounds the staging-copy threads summed over all devices.
+ * ndev > visible devices is CNT_ENODEV -- except under the TEST-ONLY hook
+ * CNT_SHARD_ALIAS_DEVICES=1 (shard k runs on device k % count, ndev <= 64), which
+ * exists so that the ndev > 1 arithmetic can be exercised on a 1-GPU box. */
 int cnt_n_to_bits_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
 int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
 /* the 5-letter codec over ndev GPUs (shards are whole 128-word tiles = 3456 nt) */
 int cnt_n_to_bits2_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
 int cnt_bits_to_n2_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
+/* The partition itself (pure arithmetic, no device needed): shard k of ndev owns
+ * nucleotides [*lo, *hi) of n_len; nt_per_word = 32 (2-bit codec: chunk = ceil(n/ndev)
+ * rounded up to 16384 nt) or 27 (5-letter codec: rounded up to 4 x 3456 nt).  Every shard
+ * starts on a word boundary, only the last non-empty one is ragged, shards past the end
+ * are empty (*lo == *hi == n_len). */
+int cnt_shard_range(size_t n_len, int ndev, int k, int nt_per_word, size_t *lo, size_t *hi);
+/* Introspection: what sharded-tier worker k was bound to by its last call -- device index,
+ * NUMA node of that device (-1 = unknown), number of CPUs it is pinned to (0 = not pinned),
+ * staging-copy threads of its pool (0 = not started).  Any pointer may be NULL.
+ * CNT_EINVAL before the first sharded call or for k >= workers. */
+int cnt_shard_worker_info(int k, int *device, int *numa_node, int *n_cpus, int *copy_threads);
+
+/* ---- multi-GPU device tier: shards already resident, one per device ---------------- */
+/* Arrays of ndev entries; shard k is device memory ON DEVICE k (ndev <= 0: all visible
+ * devices; with the test hook above: device k % count).  The calling thread enqueues every
+ * shard on a library-owned stream of its device -- the devices then run concurrently -- and
+ * returns when all have finished: no host staging, no collective, no helper threads.  Per-shard
+ * contracts are those of cnt_n_to_bits_dev / cnt_bits_to_n_dev (any alignment, ragged sizes,
+ * empty shards allowed).  shard_ms (optional, ndev floats): each shard's device time between
+ * HIP events on its stream.  The calling thread's current device is restored. */
+int cnt_n_to_bits_sharded_dev(const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words,
+                              int ndev, unsigned flags, float *shard_ms);
+int cnt_bits_to_n_sharded_dev(const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out,
+                              int ndev, unsigned flags, float *shard_ms);
+int cnt_n_to_bits2_sharded_dev(const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words,
+                               int ndev, unsigned flags, float *shard_ms);
+int cnt_bits_to_n2_sharded_dev(const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out,
+                               int ndev, unsigned flags, float *shard_ms);
 
 /* ---- device-pointer tier: what the roofline metric measures ------------------- */
 /* Pointers are device memory on the calling thread's current device.  `stream`

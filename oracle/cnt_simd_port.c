@@ -297,7 +297,9 @@ CNT_SIMD int cnt_port_bits_to_n2_pdep(const uint64_t *bits, size_t words, size_t
  * result.  This helper times `iters` calls of one function with malloc/free of
  * the output inside the timed region and returns seconds per call, so bench.py
  * can print rows that sit beside README.md:344-366 (40 000 nt, one thread).
- * fn: 0 lut 1 pext 2 shift 3 movemask 4 mul 5 memcpy | 10 lut 11 shuffle 12 pdep 13 clmul */
+ * fn: 0 lut 1 pext 2 shift 3 movemask 4 mul 5 memcpy | 10 lut 11 shuffle 12 pdep 13 clmul
+ *     20 n_to_bits2_lut 21 n_to_bits2_pext | 30 bits_to_n2_lut 31 bits_to_n2_pdep   (5-letter codec,
+ *     benches/bench_n_to_bits.rs:31-32,59-60; n_len is always the nucleotide count) */
 #include <stdlib.h>
 #include <time.h>
 
@@ -331,6 +333,18 @@ double cnt_port_time_alloc_inclusive(int fn, const void *in, size_t n_len, int i
         } else if (fn >= 10 && fn < 14) {
             uint8_t *out = (uint8_t *)aligned_alloc(32, words * 32);
             decs[fn - 10]((const uint64_t *)in, words, n_len, out);
+            sink += out[n_len - 1];
+            free(out);
+        } else if (fn == 20 || fn == 21) {
+            const size_t w2 = cnt_oracle_words2_for(n_len);
+            uint64_t *out = (uint64_t *)malloc(w2 * 8 + 8);
+            (fn == 20 ? cnt_oracle_n_to_bits2_lut : cnt_port_n_to_bits2_pext)((const uint8_t *)in, n_len, out, w2);
+            sink += out[w2 - 1];
+            free(out);
+        } else if (fn == 30 || fn == 31) {
+            const size_t w2 = cnt_oracle_words2_for(n_len);
+            uint8_t *out = (uint8_t *)malloc(w2 * 27 + 32); /* n_to_bits2.rs:202: over-allocated for the 32-B stores */
+            (fn == 30 ? cnt_oracle_bits_to_n2_lut : cnt_port_bits_to_n2_pdep)((const uint64_t *)in, w2, n_len, out);
             sink += out[n_len - 1];
             free(out);
         } else {

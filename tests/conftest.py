@@ -33,3 +33,57 @@ def kats():
 
     with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
         return json.load(f)
+
+
+# ---- full-size runs: what actually executed, at which size ------------------------------------
+# The full-size GPU tests (1 GiB, the 16 GiB metric size, 64 GiB) never change size silently: they free
+# torch's cached blocks first, then either run at the size BASELINE.json names or call pytest.skip with
+# the reason (visible in the summary).  Every run appends {test, log2_nt, ms, ...} to
+# gpurun_out/fullsize_tests.jsonl and the terminal summary prints the list, so a GPUTEST record shows
+# which sizes ran.
+FULLSIZE_RUNS = []
+FULLSIZE_LOG = os.path.join(ROOT, "gpurun_out", "fullsize_tests.jsonl")
+
+
+@pytest.fixture()
+def fullsize(request):
+    import json
+
+    def record(log2_nt, ms=None, **extra):
+        row = {"test": request.node.name, "log2_nt": log2_nt, "ms": None if ms is None else round(ms, 3)}
+        row.update(extra)
+        FULLSIZE_RUNS.append(row)
+        try:
+            os.makedirs(os.path.dirname(FULLSIZE_LOG), exist_ok=True)
+            with open(FULLSIZE_LOG, "a") as f:
+                f.write(json.dumps(row) + "\n")
+        except OSError:
+            pass
+        return row
+
+    return record
+
+
+def need_free_hbm(gib):
+    """Release torch's cached device blocks, then skip VISIBLY unless `gib` GiB of HBM are free."""
+    import gc
+
+    import torch
+
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < gib * (1 << 30):
+        pytest.skip("needs %d GiB of free HBM, %.1f of %.1f GiB are free" % (gib, free / 2**30, total / 2**30))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if FULLSIZE_RUNS:
+        terminalreporter.write_line("full-size runs (also in gpurun_out/fullsize_tests.jsonl):")
+        for r in FULLSIZE_RUNS:
+            extra = " ".join("%s=%s" % (k, v) for k, v in r.items() if k not in ("test", "log2_nt", "ms"))
+            terminalreporter.write_line("  %-58s 2^%-2d nt  %s ms  %s" % (r["test"], r["log2_nt"], r["ms"], extra))
+    skipped = terminalreporter.stats.get("skipped", [])
+    for rep in skipped:
+        terminalreporter.write_line("SKIPPED %s: %s" % (rep.nodeid, rep.longrepr[2] if isinstance(rep.longrepr, tuple) else rep.longrepr))

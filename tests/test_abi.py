@@ -135,3 +135,48 @@ def test_python_mirror_len_guard_is_a_value_error():
         bits_to_n_hip(np.zeros(1, dtype=np.uint64), 33)
     with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
         bits_to_n2_hip(np.zeros(1, dtype=np.uint64), 28)
+
+
+def test_c_partition_equals_the_python_partition(L):
+    """cnt_shard_range (what cnt_*_sharded cut by) against cute_nucleotides_amd/sharding.py (what bench.py's
+    ranks cut by): same ranges for both codecs, every shard on a word boundary, only the last non-empty one
+    ragged, empty shards at (n, n), full coverage.  Pure arithmetic: runs without a device."""
+    from cute_nucleotides_amd import _lib, sharding
+
+    sizes = [0, 1, 26, 27, 31, 32, 33, 13823, 13824, 13825, 16383, 16384, 16385, 100003, 8 * 16384, 8 * 13824 + 1,
+             (1 << 20) + 13, 1 << 34, (1 << 35) * 8, (1 << 36) + 7, (1 << 62) + 12345]
+    for unit, gran in ((32, sharding.SHARD_GRAN_NT), (27, sharding.SHARD_GRAN5_NT)):
+        assert gran % unit == 0
+        for n_len in sizes:
+            for ndev in (1, 2, 3, 4, 5, 7, 8, 64):
+                c = [sharding.shard_range_c(n_len, ndev, k, unit) for k in range(ndev)]
+                assert c == sharding.partition(n_len, ndev, gran), (unit, n_len, ndev)
+                assert c[0][0] == 0 and c[-1][1] == n_len
+                nonempty = [(lo, hi) for lo, hi in c if hi > lo]
+                for lo, hi in nonempty:
+                    assert lo % unit == 0 and lo % gran == 0
+                for lo, hi in nonempty[:-1]:
+                    assert (hi - lo) % gran == 0
+                for (lo, hi), (lo2, hi2) in zip(c, c[1:]):
+                    assert hi == lo2
+                # output words: shard k writes [lo/unit, lo/unit + ceil((hi-lo)/unit)) -- disjoint, covering ceil(n/unit)
+                w = [(lo // unit, lo // unit + -(-(hi - lo) // unit)) for lo, hi in nonempty]
+                for (a, b), (c2, d) in zip(w, w[1:]):
+                    assert b == c2
+                if nonempty:
+                    assert w[-1][1] == -(-n_len // unit)
+    # the metric / configs[4] shapes: 8 x 2^35 and 8 x 2^34 cut exactly
+    assert [sharding.shard_range_c(8 << 35, 8, k) for k in range(8)] == [(k << 35, (k + 1) << 35) for k in range(8)]
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    for bad in ((10, 0, 0, 32), (10, 2, 2, 32), (10, 2, -1, 32), (10, 2, 0, 16)):
+        assert L.cnt_shard_range(*bad, ctypes.byref(lo), ctypes.byref(hi)) == _lib.CNT_EINVAL
+    assert L.cnt_shard_range(10, 2, 0, 32, None, ctypes.byref(hi)) == _lib.CNT_EINVAL
+    # saturating near SIZE_MAX instead of wrapping
+    assert sharding.shard_range_c(2**64 - 1, 1, 0) == (0, 2**64 - 1)
+    assert sharding.shard_range_c(2**64 - 1, 3, 2)[1] == 2**64 - 1
+
+
+def test_worker_info_needs_a_sharded_call_first(L):
+    from cute_nucleotides_amd import _lib
+
+    assert L.cnt_shard_worker_info(0, None, None, None, None) == _lib.CNT_EINVAL

@@ -7,6 +7,8 @@ is integer/byte work."""
 import numpy as np
 import pytest
 
+from conftest import need_free_hbm
+
 pytestmark = pytest.mark.gpu
 
 VALID = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
@@ -41,6 +43,16 @@ def tuning():
     yield devutil
     for k, v in saved.items():
         devutil.set_tuning(k, v)
+
+
+def _timed_ms(torch, fn):
+    """device milliseconds of fn() between two events on torch's current stream (the stream the C ABI gets)"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    e1.synchronize()
+    return out, e0.elapsed_time(e1)
 
 
 def _words(hexes):
@@ -285,15 +297,19 @@ def test_device_generator_and_checksum_match_oracle(cn, oracle, torch_cuda):
 
 
 # ---- BASELINE.json configs[1], configs[2]: 1 GiB, bit-exact vs n_to_bits_lut + round trip ------
-def test_config_1gib_encode_bit_exact_and_round_trip(cn, oracle, torch_cuda):
+def test_config_1gib_encode_bit_exact_and_round_trip(cn, oracle, torch_cuda, fullsize):
     from cute_nucleotides_amd import devutil
 
     torch = torch_cuda
     n_len = 1 << 30
+    need_free_hbm(4)
     d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
     devutil.fill_random_acgt(d, 0x5EED)
-    packed = cn.n_to_bits_dev(d)
-    back = cn.bits_to_n_dev(packed, n_len)
+    packed = torch.empty(n_len // 32, dtype=torch.int64, device="cuda")
+    _, enc_ms = _timed_ms(torch, lambda: cn.n_to_bits_dev(d, out=packed))
+    back = torch.empty(n_len, dtype=torch.uint8, device="cuda")  # allocated outside the timed call
+    _, dec_ms = _timed_ms(torch, lambda: cn.bits_to_n_dev(packed, n_len, out=back))
+    fullsize(30, enc_ms + dec_ms, encode_ms=round(enc_ms, 3), decode_ms=round(dec_ms, 3), config="configs[1]+[2]", first_call=True)
     assert devutil.count_mismatch(d, back) == 0  # configs[2]: encode -> decode round trip
     host_n = oracle.fill_random_acgt(n_len, 0x5EED)  # regenerate on the host: no PCIe copy of the input
     want = oracle.n_to_bits_lut(host_n)  # the scalar parity oracle, all 2^30 nt
@@ -303,18 +319,19 @@ def test_config_1gib_encode_bit_exact_and_round_trip(cn, oracle, torch_cuda):
 
 
 # ---- metric size: 16 GiB, verified through size-independent properties ----------------------
-def test_metric_16gib_round_trip_and_checksum_of_checksums(cn, oracle, torch_cuda):
+def test_metric_16gib_round_trip_and_checksum_of_checksums(cn, oracle, torch_cuda, fullsize):
     from cute_nucleotides_amd import devutil
 
     torch = torch_cuda
     n_len = 1 << 34
-    free, _ = torch.cuda.mem_get_info()
-    if free < 40 * (1 << 30):
-        pytest.skip("needs ~36 GiB of free HBM")
+    need_free_hbm(40)  # 16 + 4 + 16 GiB resident
     d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
     devutil.fill_random_acgt(d, 0xC0FFEE)
-    packed = cn.n_to_bits_dev(d)
-    back = cn.bits_to_n_dev(packed, n_len)
+    packed = torch.empty(n_len // 32, dtype=torch.int64, device="cuda")
+    _, enc_ms = _timed_ms(torch, lambda: cn.n_to_bits_dev(d, out=packed))
+    back = torch.empty(n_len, dtype=torch.uint8, device="cuda")  # allocated outside the timed call
+    _, dec_ms = _timed_ms(torch, lambda: cn.bits_to_n_dev(packed, n_len, out=back))
+    fullsize(34, enc_ms + dec_ms, encode_ms=round(enc_ms, 3), decode_ms=round(dec_ms, 3), config="metric size", first_call=True)
     assert devutil.count_mismatch(d, back) == 0
     del back
     # checksum of checksums: per-64 MiB-chunk checksums of the packed words; sampled chunks are
@@ -334,20 +351,21 @@ def test_metric_16gib_round_trip_and_checksum_of_checksums(cn, oracle, torch_cud
 
 
 # ---- BASELINE.json configs[3]: encode + decode over a 64 GiB buffer (144 GiB resident) ----------
-def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda):
+def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda, fullsize):
     """2^36 nt needs 2^25 workgroups x 64 threads = 2^31 threads, one more than HIP allows in a
     launch, so this also covers the launcher's split into several launches."""
     from cute_nucleotides_amd import devutil
 
     torch = torch_cuda
     n_len = 1 << 36
-    free, _ = torch.cuda.mem_get_info()
-    if free < 150 * (1 << 30):
-        pytest.skip("needs ~144 GiB of free HBM")
+    need_free_hbm(150)  # 64 + 16 + 64 GiB resident
     d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
     devutil.fill_random_acgt(d, 0xBEEF)
-    packed = cn.n_to_bits_dev(d)
-    back = cn.bits_to_n_dev(packed, n_len)
+    packed = torch.empty(n_len // 32, dtype=torch.int64, device="cuda")
+    _, enc_ms = _timed_ms(torch, lambda: cn.n_to_bits_dev(d, out=packed))
+    back = torch.empty(n_len, dtype=torch.uint8, device="cuda")  # allocated outside the timed call
+    _, dec_ms = _timed_ms(torch, lambda: cn.bits_to_n_dev(packed, n_len, out=back))
+    fullsize(36, enc_ms + dec_ms, encode_ms=round(enc_ms, 3), decode_ms=round(dec_ms, 3), config="configs[3] two passes", first_call=True)
     assert devutil.count_mismatch(d, back) == 0
     del back
     chunk_nt = 16 << 20
@@ -493,24 +511,38 @@ def test_fused_round_trip_matches_two_calls(cn, oracle, torch_cuda, strict):
             assert (b[:back_off] == 0x2A).all() and (b[back_off + n_len :] == 0x2A).all()
 
 
-def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda):
-    """configs[3]: fused encode+decode over a 64 GiB buffer (144 GiB resident): the decoded copy equals
-    the input (random upper-case ACGT is its own canonical form) and the packed words carry the same
-    checksum as the plain encoder's."""
+def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
+    """configs[3]: fused encode+decode over a 64 GiB buffer (144 GiB resident, 160 GiB while the plain
+    encoder's words are held beside the fused ones): the decoded copy equals the input (random upper-case
+    ACGT is its own canonical form), the packed words equal the plain encoder's, and sampled chunks --
+    incl. the ones around the launch split at 2^36 - 64 tiles -- equal the CPU oracle's encode of the
+    host-regenerated input.  The size is never reduced: too little free HBM is a visible skip."""
     torch = torch_cuda
     from cute_nucleotides_amd import devutil
 
-    free, _ = torch.cuda.mem_get_info()
-    log2 = 36 if free > 150 * 2**30 else 33
-    n_len = (1 << log2) + 2048 * 3 + 77
+    need_free_hbm(166)  # 64 (in) + 16 (packed) + 64 (decoded) + 16 (reference words) GiB + slack
+    n_len = (1 << 36) + 2048 * 3 + 77
     d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
     devutil.fill_random_acgt(d, 36)
-    bits, back = cn.round_trip_dev(d)
+    bits = torch.empty((n_len + 31) // 32, dtype=torch.int64, device="cuda")
+    back = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    _, ms = _timed_ms(torch, lambda: cn.round_trip_dev(d, out_bits=bits, out_n=back))
+    fullsize(36, ms, config="configs[3] fused", nt=n_len, first_call=True, gbs=round(2.25 * n_len / ms / 1e6, 1))
     assert devutil.count_mismatch(d, back) == 0
     del back
     ref = cn.n_to_bits_dev(d)
     assert devutil.checksum_words(bits) == devutil.checksum_words(ref)
     assert devutil.count_mismatch(bits.view(torch.uint8), ref.view(torch.uint8)) == 0
+    del ref
+    chunk_nt = 16 << 20
+    chunk_w = chunk_nt // 32
+    n_chunks = (1 << 36) // chunk_nt
+    for c in (0, n_chunks // 3, n_chunks - 1):
+        host_n = oracle.fill_random_acgt(chunk_nt, 36, first_nt=c * chunk_nt)
+        got = bits[c * chunk_w : (c + 1) * chunk_w].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, oracle.n_to_bits_lut(host_n)), c
+    tail = oracle.fill_random_acgt(2048 * 3 + 77, 36, first_nt=1 << 36)  # the ragged end behind the fused tiles
+    assert np.array_equal(bits[(1 << 36) // 32 :].cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(tail))
 
 
 # ---- boundary behaviour of the C ABI -------------------------------------------------------

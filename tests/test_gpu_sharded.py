@@ -1,0 +1,265 @@
+"""The sharded tier with ndev > 1 (BASELINE.json configs[4]: "chunk-sharded across 8 x MI355X ... no
+collective; per-GPU outputs concatenated on the host").  The GPU box has ONE device, so these tests
+set the library's test-only hook CNT_SHARD_ALIAS_DEVICES=1 (shard k -> device k % count): the
+partition arithmetic of cnt_*_sharded, the multi-worker pool, the empty-shard path, the ragged
+last shard and the per-shard output offsets all run exactly as they would on an 8-GPU node -- only the
+device binding is folded onto cuda:0.  Everything is compared with the CPU oracle bit for bit, with
+guard words / bytes around every output.  The property this rests on is the reference's word
+independence (n_to_bits.rs:38-43: word w depends on nt [32w, 32w+32) only)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 8  # words / 64 bytes of sentinel on both sides of every output
+
+
+@pytest.fixture(scope="module")
+def L():
+    from cute_nucleotides_amd import _lib
+
+    return _lib.lib()
+
+
+@pytest.fixture()
+def alias(monkeypatch):
+    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")  # os.environ -> putenv: the C getenv sees it
+
+
+def _p(a, off_bytes=0):
+    return ctypes.c_void_p(a.ctypes.data + off_bytes)
+
+
+def _encode_sharded(L, n, ndev, five):
+    words = (n.size + 26) // 27 if five else (n.size + 31) // 32
+    buf = np.full(words + 2 * GUARD, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
+    fn = L.cnt_n_to_bits2_sharded if five else L.cnt_n_to_bits_sharded
+    rc = fn(_p(n) if n.size else None, n.size, _p(buf, 8 * GUARD), words, ndev)
+    assert rc == 0, rc
+    assert (buf[:GUARD] == 0xA5A5A5A5A5A5A5A5).all() and (buf[GUARD + words :] == 0xA5A5A5A5A5A5A5A5).all(), "guard words overwritten"
+    return buf[GUARD : GUARD + words].copy()
+
+
+def _decode_sharded(L, bits, length, ndev, five):
+    buf = np.full(length + 128, 0x2A, dtype=np.uint8)
+    fn = L.cnt_bits_to_n2_sharded if five else L.cnt_bits_to_n_sharded
+    rc = fn(_p(bits) if bits.size else None, bits.size, length, _p(buf, 64), ndev)
+    assert rc == 0, rc
+    assert (buf[:64] == 0x2A).all() and (buf[64 + length :] == 0x2A).all(), "guard bytes overwritten"
+    return buf[64 : 64 + length].copy()
+
+
+# sizes chosen against the 16384-nt (13824-nt) shard granule: below one granule in total (every shard but
+# the first is empty), one granule + a bit with 8 shards (6 empty), whole granules only, a ragged last
+# shard, fewer granules than shards, and sizes past the host tier's zero-copy limit (2^20 nt per shard)
+# so the double-buffered pipeline runs inside every worker
+SIZES2 = [1, 31, 33, 5000, 16384, 16385, 3 * 16384, 16384 * 8, 16384 * 8 + 1, 100003, (1 << 22) + 13, (1 << 24) + 16384 * 3 + 77]
+SIZES5 = [1, 26, 27, 28, 5000, 13824, 13825, 3 * 13824, 13824 * 8 + 5, 100003, (1 << 22) + 13, 27 * (1 << 19) + 13824 * 3 + 11]
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 4, 8])
+def test_sharded_2bit_ndev_gt_1_matches_the_oracle(L, oracle, alias, ndev):
+    from cute_nucleotides_amd import sharding
+
+    for n_len in SIZES2:
+        n = oracle.fill_random_acgt(n_len, 1000 + n_len % 997)
+        want = oracle.n_to_bits_lut(n)
+        got = _encode_sharded(L, n, ndev, five=False)
+        assert np.array_equal(got, want), (ndev, n_len)
+        back = _decode_sharded(L, got, n_len, ndev, five=False)
+        assert np.array_equal(back, oracle.bits_to_n_lut(want, n_len)), (ndev, n_len)
+        # decode of a prefix: len < 32 * words, shards are cut by `len`, not by the words passed
+        if n_len > 40:
+            part = _decode_sharded(L, got, n_len - 37, ndev, five=False)
+            assert np.array_equal(part, n[: n_len - 37]), (ndev, n_len)
+    # the partition really had empty and ragged shards in this sweep
+    parts = [sharding.shard_range_c(16385, 8, k) for k in range(8)]
+    assert parts[0] == (0, 16384) and parts[1] == (16384, 16385) and all(p == (16385, 16385) for p in parts[2:])
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 4, 8])
+def test_sharded_5letter_ndev_gt_1_matches_the_oracle(L, oracle, alias, ndev):
+    for n_len in SIZES5:
+        n = oracle.fill_random_acgtn(n_len, 2000 + n_len % 991)
+        want = oracle.n_to_bits2_lut(n)
+        got = _encode_sharded(L, n, ndev, five=True)
+        assert np.array_equal(got, want), (ndev, n_len)
+        back = _decode_sharded(L, got, n_len, ndev, five=True)
+        assert np.array_equal(back, oracle.bits_to_n2_lut(want, n_len)), (ndev, n_len)
+
+
+def test_sharded_off_alphabet_bytes_and_lowercase(L, oracle, alias):
+    """every shard goes through the same default semantics as the unsharded call: (byte>>1)&3 on ALL bytes"""
+    rng = np.random.default_rng(5)
+    n = rng.integers(0, 256, 16384 * 5 + 321, dtype=np.uint8)
+    whole = np.empty((n.size + 31) // 32, dtype=np.uint64)
+    assert L.cnt_n_to_bits(_p(n), n.size, _p(whole), whole.size) == 0
+    for ndev in (2, 5, 8):
+        assert np.array_equal(_encode_sharded(L, n, ndev, five=False), whole)
+    low = np.frombuffer(b"acgtu" * 20000, dtype=np.uint8)
+    assert np.array_equal(_encode_sharded(L, low, 4, five=False), oracle.n_to_bits_lut(low))
+
+
+def test_alias_hook_is_opt_in_and_bounded(L, oracle, monkeypatch):
+    import torch
+
+    from cute_nucleotides_amd import _lib
+
+    count = torch.cuda.device_count()
+    n = oracle.fill_random_acgt(40000, 3)
+    out = np.zeros(1250, dtype=np.uint64)
+    monkeypatch.delenv("CNT_SHARD_ALIAS_DEVICES", raising=False)
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, count + 1) == _lib.CNT_ENODEV  # production behaviour
+    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 65) == _lib.CNT_ENODEV  # the hook stops at 64 shards
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 64) == 0
+    assert np.array_equal(out, oracle.n_to_bits_lut(n))
+    # argument errors come before any device work, as for the unsharded calls
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), 1249, 4) == _lib.CNT_ECAP
+    assert L.cnt_bits_to_n_sharded(_p(out), 1250, 40001, _p(n), 4) == _lib.CNT_ELEN
+    assert L.cnt_bits_to_n2_sharded(_p(out), 1250, 1250 * 27 + 1, _p(n), 4) == _lib.CNT_ELEN
+
+
+def test_worker_placement_and_copy_thread_budget(L, oracle, alias, monkeypatch):
+    """worker k is bound to device k % count; its staging-copy pool is sized so that the total over
+    all shards stays within CNT_SHARD_COPY_THREADS_TOTAL; when the platform names the GPU's NUMA node the
+    worker is pinned to that node's CPUs (and never to CPUs outside the process's own mask)."""
+    import os
+
+    import torch
+
+    from cute_nucleotides_amd import sharding
+
+    count = torch.cuda.device_count()
+    n = oracle.fill_random_acgt(8 * (16 << 20) + 5, 11)  # >= 16 Mi nt per shard: 4-MiB staging copies, so the pools start
+    want = oracle.n_to_bits_lut(n)
+    allowed = len(os.sched_getaffinity(0))
+    for ndev, total in ((8, 32), (8, 8), (2, 32), (3, 2)):
+        monkeypatch.setenv("CNT_SHARD_COPY_THREADS_TOTAL", str(total))
+        assert np.array_equal(_encode_sharded(L, n, ndev, five=False), want)
+        used = 0
+        for k in range(ndev):
+            info = sharding.worker_info(k)
+            assert info["device"] == k % count
+            assert info["numa_node"] >= -1
+            assert 0 <= info["n_cpus"] <= allowed
+            if info["numa_node"] < 0:
+                assert info["n_cpus"] == 0  # unknown node -> not pinned
+            assert 1 <= info["copy_threads"] <= max(1, min(4, total // ndev)), info
+            used += info["copy_threads"]
+        assert used <= max(total, ndev)
+    monkeypatch.setenv("CNT_SHARD_NUMA", "0")  # only consulted when a worker (re)binds; results never depend on it
+    assert np.array_equal(_encode_sharded(L, n, 8, five=False), want)
+
+
+def test_sharded_calls_interleave_with_shutdown_and_other_tiers(L, oracle, alias):
+    import threading
+
+    n = oracle.fill_random_acgt((1 << 21) + 99, 21)
+    want = oracle.n_to_bits_lut(n)
+    for ndev in (8, 2, 5, 8):
+        assert np.array_equal(_encode_sharded(L, n, ndev, five=False), want)
+        assert L.cnt_shutdown() == 0  # releases the workers' streams / staging; the next call rebuilds them
+    bad = []
+
+    def caller(seed):  # concurrent sharded callers queue on the pool; unsharded host-tier calls run beside them
+        m = oracle.fill_random_acgt(200000 + 1000 * seed, seed)
+        w = oracle.n_to_bits_lut(m)
+        for _ in range(3):
+            if not np.array_equal(_encode_sharded(L, m, 2 + seed, five=False), w):
+                bad.append(seed)
+            one = np.empty(w.size, dtype=np.uint64)
+            if L.cnt_n_to_bits(_p(m), m.size, _p(one), one.size) != 0 or not np.array_equal(one, w):
+                bad.append(-seed)
+
+    ts = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+
+
+# ---- device-resident sharded tier ----------------------------------------------------------
+@pytest.mark.parametrize("ndev", [1, 2, 3, 8])
+def test_device_resident_shards_match_the_oracle(L, oracle, alias, monkeypatch, ndev):
+    """cnt_*_sharded_dev: one entry per shard, shards of different (ragged, empty, misaligned) sizes, every
+    one checked against the oracle; the per-shard device times come back positive."""
+    import torch
+
+    from cute_nucleotides_amd import sharding
+
+    if ndev == 1:
+        monkeypatch.delenv("CNT_SHARD_ALIAS_DEVICES")  # the production path: one real device, no hook
+    sizes = [(1 << 21) + 13, 0, 40000, 2048 * 5, 77, (1 << 20), 16384 * 3 + 1, 1][:ndev]
+    for five in (False, True):
+        gen = oracle.fill_random_acgtn if five else oracle.fill_random_acgt
+        enc = oracle.n_to_bits2_lut if five else oracle.n_to_bits_lut
+        dec = oracle.bits_to_n2_lut if five else oracle.bits_to_n_lut
+        host = [gen(s, 50 + k) if s else np.empty(0, dtype=np.uint8) for k, s in enumerate(sizes)]
+        bufs = [torch.zeros(s + 64, dtype=torch.uint8, device="cuda") for s in sizes]
+        shards = []
+        for k, (b, h) in enumerate(zip(bufs, host)):
+            v = b[(k % 3) : (k % 3) + h.size]  # pointer phases 0, 1, 2: the any-alignment plan per shard
+            if h.size:
+                v.copy_(torch.from_numpy(h))
+            shards.append(v)
+        outs, ms = sharding.n_to_bits_sharded_dev(shards, five_letter=five, want_ms=True)
+        assert len(ms) == len(sizes)
+        for k, (o, h) in enumerate(zip(outs, host)):
+            want = enc(h) if h.size else np.empty(0, dtype=np.uint64)
+            assert np.array_equal(o.cpu().numpy().view(np.uint64), want), (five, ndev, k)
+            assert ms[k] >= 0.0 and (ms[k] > 0.0 or h.size == 0)
+        backs = sharding.bits_to_n_sharded_dev(outs, sizes, five_letter=five)
+        for k, (b, h) in enumerate(zip(backs, host)):
+            want = dec(enc(h), h.size) if h.size else np.empty(0, dtype=np.uint8)
+            assert np.array_equal(b.cpu().numpy(), want), (five, ndev, k)
+        # strict-LUT flag reaches every shard
+        if not five:
+            raw = [torch.from_numpy(np.random.default_rng(k).integers(0, 256, max(s, 1), dtype=np.uint8)).cuda() for k, s in enumerate(sizes)]
+            outs = sharding.n_to_bits_sharded_dev(raw, strict_lut=True)
+            for o, r in zip(outs, raw):
+                assert np.array_equal(o.cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(r.cpu().numpy()))
+    assert torch.cuda.current_device() == 0
+
+
+def test_device_resident_shards_error_paths(L, oracle, alias):
+    import torch
+
+    from cute_nucleotides_amd import _lib, sharding
+
+    a = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        sharding.n_to_bits_sharded_dev([a, a], outs=[torch.zeros(128, dtype=torch.int64, device="cuda"), torch.zeros(3, dtype=torch.int64, device="cuda")])
+    with pytest.raises(ValueError, match="The length is greater"):
+        sharding.bits_to_n_sharded_dev([torch.zeros(4, dtype=torch.int64, device="cuda")], [129])
+    # the C level reports the first failing shard's status after waiting for the shards already enqueued
+    ptr = (ctypes.c_void_p * 2)(a.data_ptr(), a.data_ptr())
+    n_len = (ctypes.c_size_t * 2)(4096, 4096)
+    o = torch.zeros(256, dtype=torch.int64, device="cuda")
+    optr = (ctypes.c_void_p * 2)(o.data_ptr(), o.data_ptr() + 1024)
+    caps = (ctypes.c_size_t * 2)(128, 127)
+    assert L.cnt_n_to_bits_sharded_dev(ptr, n_len, optr, caps, 2, 0, None) == _lib.CNT_ECAP
+    assert L.cnt_n_to_bits_sharded_dev(None, n_len, optr, caps, 2, 0, None) == _lib.CNT_EINVAL
+    assert L.cnt_n_to_bits_sharded_dev(ptr, n_len, optr, caps, 65, 0, None) == _lib.CNT_ENODEV
+
+
+def test_sharded_host_tier_throughput_is_sane(L, oracle, alias):
+    """not a benchmark (one GPU behind all shards): eight aliased shards of a 2^28-nt buffer must not be
+    pathologically slower than the unsharded call -- catches a pool that serialises or re-pins per call"""
+    import time
+
+    n = oracle.fill_random_acgt(1 << 28, 7)
+    out = np.empty(1 << 23, dtype=np.uint64)
+    L.cnt_n_to_bits(_p(n), n.size, _p(out), out.size)
+    t0 = time.perf_counter()
+    assert L.cnt_n_to_bits(_p(n), n.size, _p(out), out.size) == 0
+    t_one = time.perf_counter() - t0
+    want = out.copy()
+    L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 8)
+    out[:] = 0
+    t0 = time.perf_counter()
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 8) == 0
+    t_eight = time.perf_counter() - t0
+    assert np.array_equal(out, want)
+    assert t_eight < 4.0 * t_one + 0.05, (t_one, t_eight)

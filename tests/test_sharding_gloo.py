@@ -51,6 +51,7 @@ def _worker(rank, world, port, n_len, seed, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lo, hi = sharding.partition(n_len, world)[rank]
+        assert (lo, hi) == sharding.shard_range_c(n_len, world, rank)  # the C library cuts at the same places
         mine = orc.fill_random_acgt(hi - lo, seed, first_nt=lo)  # each rank generates only its chunk
         bits = orc.n_to_bits_lut(mine)
         w_lo, w_hi = sharding.word_range(lo, hi)
