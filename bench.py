@@ -16,6 +16,12 @@ rank r owns chunk r (cute_nucleotides_amd/sharding.py); there is no data-path co
 the process group (gloo over loopback by default, RCCL with CNT_BENCH_BACKEND=nccl) is only used
 for the barrier and the max-over-ranks of the timing.  Weak scaling: per-GPU work is fixed.
 
+The per-GPU size stays 2^34 nt (the metric's 16 GiB) at every N, so the driver's N = 1, 2, 4, 8 values form a
+weak-scaling curve; BASELINE.json configs[4] (256 GiB over 8 GPUs = 2^35 nt per GPU) is measured in the same run
+as `configs4_shard` (encode of a 2^35-nt shard on every rank, per-GPU and aggregate Gnt/s).  `ranks` lists every
+rank's device (index, PCI address, UUID, NUMA node, visible-device count) and its own kernel times, so an N-GPU
+line shows N distinct devices and no data-path collective.
+
 Rank 0 prints ONE JSON line.  `value` counts every nucleotide converted per second over all
 ranks (N encoded + N decoded per step and rank), inputs already in HBM.  `roofline` is for
 the n_to_bits encode kernel (the north-star target), `roofline_decode` for bits_to_n; both
@@ -25,8 +31,11 @@ launch stream.  `cpu_baseline` times the oracle's ports of the reference's faste
 paths (n_to_bits_movemask / bits_to_n_shuffle) on this box's host cores, rank 0, N=1 only.
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -47,7 +56,29 @@ def parse_args():
     p.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     p.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline time budget (0 = skip)")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="headline only: skip the ceilings, the configs block and the fused pass")
+    p.add_argument("--shard-log2-nt", type=int, default=35, help="per-GPU shard of BASELINE.json configs[4] (256 GiB over 8 GPUs = 2^35 nt each)")
     return p.parse_args()
+
+
+def physical_cores(cpus):
+    """distinct (package, core) pairs among the CPUs this process may run on"""
+    seen = set()
+    for c in cpus:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            return None
+    return len(seen)
+
+
+def sockets():
+    try:
+        return len({open(os.path.join(d, "topology", "physical_package_id")).read().strip()
+                    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*") if os.path.exists(os.path.join(d, "topology"))})
+    except OSError:
+        return None
 
 
 def cpu_baseline(seconds):
@@ -66,7 +97,8 @@ def cpu_baseline(seconds):
         return {"value": None, "unit": "Gnt/s", "cores": 0, "kind": "port", "sample": "host CPU lacks AVX2/BMI2"}
     L = orc.lib()
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    cores = len(cpus)
+    cores = len(cpus)  # logical CPUs = timed threads
+    physical = physical_cores(cpus)
     per_thread = 16 << 20  # 16 Mi nt per thread: past any per-core share of L2/L3
     n_len = max(1 << 28, cores * per_thread)
     n = np.empty(n_len, dtype=np.uint8)
@@ -144,10 +176,40 @@ def cpu_baseline(seconds):
         L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, 40000, 2000)  # warm-up
         per = L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, 40000, 20000 if fn not in (0, 10) else 4000)
         faithful[name] = round(40000 / per / 2**30, 3)
+    # the 5-letter groups of the same harness (bench_n_to_bits.rs:26-35,53-63: "ATCGN" x 8000), README.md:374-377
+    n5 = np.frombuffer(b"ATCGN" * 8000, dtype=np.uint8).copy()
+    b5 = np.empty(L.cnt_oracle_words2_for(40000), dtype=np.uint64)
+    L.cnt_oracle_n_to_bits2_lut(n5.ctypes.data, 40000, b5.ctypes.data, b5.size)
+    for fn, name in {20: "n_to_bits2_lut", 21: "n_to_bits2_pext", 30: "bits_to_n2_lut", 31: "bits_to_n2_pdep"}.items():
+        src = n5 if fn < 30 else b5
+        L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, 40000, 1000)
+        per = L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, 40000, 10000 if fn in (21, 31) else 3000)
+        faithful[name] = round(40000 / per / 2**30, 3)
+    # the same allocation-inclusive single-thread calls at 1 MiB and 1 GiB of random ACGT
+    # (DRAM-resident at 1 GiB; every call pays the page faults of its fresh output, like a fresh Vec)
+    faithful_big = {}
+    for log2 in (20, 30):
+        m = 1 << log2
+        if m > n_len:
+            continue
+        L.cnt_port_n_to_bits_movemask(n.ctypes.data, m, bits.ctypes.data, m // 32)
+        row = {}
+        for fn, name in names.items():
+            src = n if fn < 10 else bits
+            slow = fn in (0, 10)
+            iters = (200 if not slow else 20) if log2 == 20 else (3 if not slow else 1)
+            if log2 == 20:
+                L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, m, 5)
+            per = L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, m, iters)
+            row[name] = round(m / per / 2**30, 3)
+        faithful_big["2^%d" % log2] = row
     both = lambda e, d: 2.0 / (1.0 / e + 1.0 / d)  # nt converted per second over an encode pass + a decode pass
     return {
         "reference_faithful_40k_GiBs": faithful,
+        "reference_faithful_GiBs_1thread_alloc_inclusive": faithful_big,
         "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
+        "cores_detail": {"threads_timed": cores, "logical_cpus": cores, "physical_cores": physical,
+                         "sockets": sockets(), "note": "`cores` = timed threads = logical CPUs (SMT siblings included)"},
         "sample": "%d Mi random ACGT nt (%d pinned threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
                   "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"
                   % (n_len >> 20, cores, seconds),
@@ -158,8 +220,72 @@ def cpu_baseline(seconds):
     }
 
 
+def stats_ms(ms):
+    return {"mean": round(statistics.fmean(ms), 4), "median": round(statistics.median(ms), 4), "min": round(min(ms), 4),
+            "max": round(max(ms), 4), "n": len(ms)}
+
+
+def gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9
+
+
+def timed_calls(torch, fn, iters, warm=1):
+    """[ms] of `iters` individual fn() calls, each between two HIP events on torch's current stream (the stream
+    the C ABI is handed)."""
+    for _ in range(warm):
+        fn()
+    out = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return out
+
+
+def numpy_pack(n):
+    """(byte>>1)&3, 32 codes per u64, LSB first (n_to_bits.rs:38-43, :85) -- three lines of numpy for the sampled
+    check of the TIMED packed buffer; bench.py touches oracle/ only in cpu_baseline()"""
+    import numpy as np
+
+    c = ((n >> 1) & 3).astype(np.uint64).reshape(-1, 32)
+    return (c << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+
+
+def load_probes():
+    """bench/libcnt_probes.so (built by __graft_entry__.build(), travels with the snapshot): no-arithmetic streams
+    issued like the shipped kernels, for the same-run ceilings.  None if it is not there."""
+    path = os.path.join(ROOT, "bench", "libcnt_probes.so")
+    if not os.path.exists(path):
+        return None
+    P = ctypes.CDLL(path)
+    P.probe_shipped.restype = ctypes.c_int
+    P.probe_shipped.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    return P
+
+
+def measure_ceilings(torch, P, d_a, d_b, nbytes, iters=5):
+    """TB/s (decimal) of the five no-arithmetic streams over the headline's own buffers: d_a is only read, d_b is
+    overwritten (call after verification).  nbytes = the 16-B-per-lane side (the ASCII side of the codec)."""
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = {}
+    for name, kind, moved in (("read_only", 0, nbytes), ("write_only", 4, nbytes), ("copy_1to1", 1, 2 * nbytes),
+                              ("read4_write1_encode_shape", 2, 1.25 * nbytes), ("read1_write4_decode_shape", 3, 1.25 * nbytes)):
+        def call():
+            rc = P.probe_shipped(kind, d_a.data_ptr(), d_b.data_ptr(), nbytes, stream)
+            if rc:
+                raise RuntimeError("probe_shipped(%d) -> %d" % (kind, rc))
+        ms = timed_calls(torch, call, iters)
+        rows[name] = {"GBs": round(gbs(moved, statistics.median(ms)), 1), "best_GBs": round(gbs(moved, min(ms)), 1),
+                      "bytes_moved": int(moved), "ms_median": round(statistics.median(ms), 4)}
+    return rows
+
+
 def main():
     args = parse_args()
+    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,11 +300,12 @@ def main():
     # Test hooks (never set by the driver): CNT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # CNT_BENCH_BACKEND=gloo swaps the process group's backend, so the N>1 code path can be
     # exercised on a 1-GPU box (RCCL refuses two ranks on one device).
-    if os.environ.get("CNT_BENCH_SHARE_GPU") == "1":
+    shared_gpu = os.environ.get("CNT_BENCH_SHARE_GPU") == "1"
+    if shared_gpu:
         local_rank = 0
-    # The process group carries no data: it is the barrier + a MAX/MIN of two scalars.  gloo over
-    # loopback is the default because it needs no GPU IPC and has been exercised with 2 ranks on the
-    # GPU box (tests/test_gpu_bench.py); CNT_BENCH_BACKEND=nccl runs the same control plane over RCCL.
+    # The process group carries no data: it is the barrier + a MAX/MIN of a few scalars + one gather of the
+    # per-rank report rows.  gloo over loopback is the default because it needs no GPU IPC and has been exercised
+    # with 2 ranks on the GPU box (tests/test_gpu_bench.py); CNT_BENCH_BACKEND=nccl runs the same control plane over RCCL.
     backend = os.environ.get("CNT_BENCH_BACKEND", "gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -210,9 +337,18 @@ def main():
     import cute_nucleotides_amd as cn
     from cute_nucleotides_amd import devutil, sharding
 
+    # ---- who am I: the device this rank drives ------------------------------------------------------
+    ident = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    ident.update(devutil.device_identity(local_rank))
+    props = torch.cuda.get_device_properties(local_rank)
+    ident["name"] = props.name
+    ident["uuid"] = str(getattr(props, "uuid", "")) or None
+    ident["hbm_GiB"] = round(props.total_memory / 2**30, 1)
+
     n_per = 1 << args.log2_nt
     n_global = n_per * world
     lo, hi = sharding.partition(n_global, world)[rank]  # contiguous chunk on a word boundary
+    assert (lo, hi) == sharding.shard_range_c(n_global, world, rank)  # the C library cuts at the same places
     n_len = hi - lo
     words = cn.n_to_bits.words_for(n_len)
 
@@ -231,6 +367,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def allreduce(values, op):
+        t = torch.tensor(values, dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return [float(x) for x in t.tolist()]
+
     for _ in range(args.warmup):
         step()
 
@@ -248,64 +390,177 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    dec_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
-    # slowest rank's per-kernel averages (for the aggregate encode / decode rates); rank 0's own
-    # times stay in `roofline*`, which describe one GPU
-    km = torch.tensor([enc_ms, dec_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-    enc_ms_max, dec_ms_max = float(km[0].item()), float(km[1].item())
+    elapsed = allreduce([elapsed], dist.ReduceOp.MAX)[0]
+    enc_list = [e[0].elapsed_time(e[1]) for e in ev]
+    dec_list = [e[1].elapsed_time(e[2]) for e in ev]
+    enc_ms, dec_ms = statistics.fmean(enc_list), statistics.fmean(dec_list)
+    # slowest rank's per-kernel averages (for the aggregate encode / decode rates); each rank's own times go
+    # into its `ranks` row, rank 0's into `roofline*`, which describe one GPU
+    enc_ms_max, dec_ms_max = allreduce([enc_ms, dec_ms], dist.ReduceOp.MAX)
 
-    # BASELINE.json configs[3] in passing: the FUSED round trip (cnt_round_trip_dev) over the same
-    # buffers, outside the timed region -- reported beside the headline, never part of `value`
-    fused_ms = None
-    if world == 1:
-        fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        cn.round_trip_dev(d_in, out_bits=d_packed, out_n=d_out)
-        fe[0].record()
-        for _ in range(3):
-            cn.round_trip_dev(d_in, out_bits=d_packed, out_n=d_out)
-        fe[1].record()
-        fe[1].synchronize()
-        fused_ms = fe[0].elapsed_time(fe[1]) / 3
-
-    verified = None
+    # ---- verification of the TIMED buffers, before anything else writes them --------------------------
+    # Outside the timed region, and WITHOUT the oracle (bench.py may touch oracle/ only in its cpu_baseline
+    # leg; bit-exact parity against the oracle is what tests/ -m gpu establish):
+    #  (1) the timed buffers round-trip: decode(encode(x)) == x, compared on the device;
+    #  (2) the first and last 2^20 nt of the timed packed buffer equal a numpy restatement of the layout;
+    #  (3) the reference's periodic bench input (benches/bench_n_to_bits.rs:68-70, "ATCG" repeated) at 2^20 nt --
+    #      a whole number of tiles and past the small-input path, so it runs the SAME stream kernels as the
+    #      timed region -- encodes to 0xD8D8D8D8D8D8D8D8 words (the reference's unit-test vector,
+    #      n_to_bits.rs:414-415) and decodes back.
+    verified, packed_sum = None, None
     if not args.no_verify:
-        # Outside the timed region, and WITHOUT the oracle (bench.py may touch oracle/ only in its
-        # cpu_baseline leg; bit-exact parity against the oracle is what tests/ -m gpu establish):
-        #  (1) the timed buffers round-trip: decode(encode(x)) == x, compared on the device;
-        #  (2) the reference's own bench input (benches/bench_n_to_bits.rs:68-78, "ATCG" x 10000)
-        #      encodes to 1250 x 0xD8D8D8D8D8D8D8D8 -- the reference's unit-test vector
-        #      (n_to_bits.rs:414-415) -- through the same kernels, and decodes back.
-        import numpy as np
-
         ok = devutil.count_mismatch(d_in, d_out) == 0
-        kat = torch.from_numpy(np.frombuffer(b"ATCG" * 10000, dtype=np.uint8).copy()).to(dev)
+        packed_sum = devutil.checksum_words(d_packed)
+        m = min(1 << 20, n_len // 32 * 32)
+        for off in (0, (n_len - m) // 32 * 32):
+            host_n = d_in[off : off + m].cpu().numpy()
+            got = d_packed[off // 32 : (off + m) // 32].cpu().numpy().view(np.uint64)
+            ok = ok and bool(np.array_equal(got, numpy_pack(host_n)))
+        kat = torch.from_numpy(np.frombuffer(b"ATCG" * (1 << 18), dtype=np.uint8).copy()).to(dev)
+        assert kat.numel() % 4096 == 0 and kat.numel() > devutil.get_tuning("small_nt")
         kat_bits = cn.n_to_bits_dev(kat)
-        ok = ok and bool((kat_bits.cpu().numpy().view(np.uint64) == np.uint64(0xD8D8D8D8D8D8D8D8)).all()) and kat_bits.numel() == 1250
-        ok = ok and bool(torch.equal(cn.bits_to_n_dev(kat_bits, 40000), kat))
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        verified = bool(flag.item())
+        ok = ok and bool((kat_bits.cpu().numpy().view(np.uint64) == np.uint64(0xD8D8D8D8D8D8D8D8)).all()) and kat_bits.numel() == 1 << 15
+        ok = ok and bool(torch.equal(cn.bits_to_n_dev(kat_bits, kat.numel()), kat))
+        del kat, kat_bits
+        verified = ok
+
+    extras = not args.no_extras
+    # ---- BASELINE.json configs[3] in passing: the FUSED round trip over the same buffers -------------------
+    fused = None
+    if extras:
+        fl = timed_calls(torch, lambda: cn.round_trip_dev(d_in, out_bits=d_packed, out_n=d_out), 5)
+        fused = stats_ms(fl)
+        if verified is not None:  # the fused kernel's own outputs: same packed words, same decoded text
+            fused["verified"] = devutil.count_mismatch(d_in, d_out) == 0 and devutil.checksum_words(d_packed) == packed_sum
+            verified = verified and fused["verified"]
+
+    # ---- BASELINE.json configs[1] / [2]: 1 GiB, on the first 2^30 nt of the same buffers ---------------------
+    configs = {}
+    if extras and n_len >= (1 << 30):
+        m = 1 << 30
+        e30 = timed_calls(torch, lambda: cn.n_to_bits_dev(d_in[:m], out=d_packed[: m // 32]), 10, warm=2)
+        d30 = timed_calls(torch, lambda: cn.bits_to_n_dev(d_packed[: m // 32], m, out=d_out[:m]), 10, warm=2)
+        for key, lst in (("configs[1] n_to_bits encode, 1 GiB (2^30 nt)", e30), ("configs[2] bits_to_n decode, 1 GiB (2^30 nt)", d30)):
+            st = stats_ms(lst)
+            configs[key] = {"ms": st, "gnts": round(m / (st["median"] * 1e-3) / 1e9, 1),
+                            "achieved_GBs": round(gbs(BYTES_PER_NT * m, st["median"]), 1),
+                            "frac": round(gbs(BYTES_PER_NT * m, st["median"]) / HBM_PEAK_GBS, 4)}
+        if verified is not None:
+            configs["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]["round_trip_verified"] = devutil.count_mismatch(d_in[:m], d_out[:m]) == 0
+
+    # ---- same-run, same-box ceilings: no-arithmetic streams issued like the shipped kernels -------
+    ceilings = None
+    if extras:
+        P = load_probes()
+        if P is not None and n_len % 16384 == 0 and n_len <= (1 << 35):
+            ceilings = measure_ceilings(torch, P, d_in, d_out, n_len)
+        else:
+            ceilings = {"error": "bench/libcnt_probes.so not built (run __graft_entry__.build())" if P is None else "size not probe-able"}
+
+    # ---- BASELINE.json configs[4]: this rank's shard of "256 GiB over 8 GPUs" = 2^35 nt, encode ---------------
+    shard = None
+    del d_out, d_packed, d_in
+    torch.cuda.empty_cache()
+    if extras and args.shard_log2_nt > 0:
+        s_len = 1 << args.shard_log2_nt
+        free, _ = torch.cuda.mem_get_info()
+        need = 2.3 * s_len + (4 << 30)
+        fits = allreduce([1.0 if free > need else 0.0], dist.ReduceOp.MIN)[0] == 1.0  # every rank takes the same branch
+        if fits:
+            s_lo, s_hi = sharding.shard_range_c(s_len * world, world, rank)
+            s_in = torch.empty(s_hi - s_lo, dtype=torch.uint8, device=dev)
+            s_packed = torch.empty((s_hi - s_lo) // 32, dtype=torch.int64, device=dev)
+            devutil.fill_random_acgt(s_in, args.seed + 4, first_nt=s_lo)
+            sl = timed_calls(torch, lambda: cn.n_to_bits_dev(s_in, out=s_packed), 8, warm=2)
+            # all ranks at once, wall clock between barriers: what "aggregate" means for the sharded job
+            reps = 8
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                cn.n_to_bits_dev(s_in, out=s_packed)
+            barrier()
+            wall = allreduce([time.perf_counter() - t0], dist.ReduceOp.MAX)[0]
+            shard = {"nt": s_hi - s_lo, "first_nt": s_lo, "encode_ms": stats_ms(sl), "wall_ms_per_encode_all_ranks": round(wall / reps * 1e3, 4)}
+            if verified is not None:
+                s_back = cn.bits_to_n_dev(s_packed, s_hi - s_lo)
+                shard["round_trip_verified"] = devutil.count_mismatch(s_in, s_back) == 0
+                verified = verified and shard["round_trip_verified"]
+                del s_back
+            del s_in, s_packed
+            torch.cuda.empty_cache()
+        else:
+            shard = {"skipped": "needs %.0f GiB of free HBM on every rank, %.0f free here" % (need / 2**30, free / 2**30)}
+
+    # ---- BASELINE.json configs[3] at its own size: 64 GiB (2^36 nt), two passes and fused, N = 1 only --------
+    if extras and world == 1:
+        b_len = 1 << 36
+        free, _ = torch.cuda.mem_get_info()
+        key2, keyf = "configs[3] encode + decode as two passes, 64 GiB (2^36 nt)", "configs[3] fused round trip, 64 GiB (2^36 nt)"
+        if free > 150 * 2**30:
+            b_in = torch.empty(b_len, dtype=torch.uint8, device=dev)
+            b_packed = torch.empty(b_len // 32, dtype=torch.int64, device=dev)
+            b_out = torch.empty(b_len, dtype=torch.uint8, device=dev)
+            devutil.fill_random_acgt(b_in, args.seed + 3)
+            be = timed_calls(torch, lambda: cn.n_to_bits_dev(b_in, out=b_packed), 3)
+            bd = timed_calls(torch, lambda: cn.bits_to_n_dev(b_packed, b_len, out=b_out), 3)
+            ok2 = devutil.count_mismatch(b_in, b_out) == 0 if verified is not None else None
+            two_sum = devutil.checksum_words(b_packed) if verified is not None else None
+            b_out.zero_()
+            bf = timed_calls(torch, lambda: cn.round_trip_dev(b_in, out_bits=b_packed, out_n=b_out), 3)
+            okf = (devutil.count_mismatch(b_in, b_out) == 0 and devutil.checksum_words(b_packed) == two_sum) if verified is not None else None
+            t2 = statistics.median(be) + statistics.median(bd)
+            configs[key2] = {"encode_ms": stats_ms(be), "decode_ms": stats_ms(bd), "bytes_per_nt": 2.5, "resident_GiB": 144,
+                             "nt_converted_gnts": round(2 * b_len / (t2 * 1e-3) / 1e9, 1), "achieved_GBs": round(gbs(2.5 * b_len, t2), 1),
+                             "frac": round(gbs(2.5 * b_len, t2) / HBM_PEAK_GBS, 4), "round_trip_verified": ok2}
+            tf = statistics.median(bf)
+            configs[keyf] = {"ms": stats_ms(bf), "bytes_per_nt": 2.25, "resident_GiB": 144,
+                             "nt_converted_gnts": round(2 * b_len / (tf * 1e-3) / 1e9, 1), "achieved_GBs": round(gbs(2.25 * b_len, tf), 1),
+                             "frac": round(gbs(2.25 * b_len, tf) / HBM_PEAK_GBS, 4), "verified_against_two_passes": okf}
+            if verified is not None:
+                verified = verified and ok2 and okf
+            del b_in, b_packed, b_out
+            torch.cuda.empty_cache()
+        else:
+            configs[key2] = configs[keyf] = {"skipped": "needs 150 GiB of free HBM, %.0f GiB free" % (free / 2**30)}
+
+    if verified is not None:
+        verified = bool(allreduce([1.0 if verified else 0.0], dist.ReduceOp.MIN)[0] == 1.0)
+
+    # ---- one report row per rank, gathered through the control plane (no data-path collective anywhere) ------
+    enc_st, dec_st = stats_ms(enc_list), stats_ms(dec_list)
+    row = dict(ident)
+    row.update({
+        "nt": n_len, "first_nt": lo,
+        "encode_ms": enc_st, "decode_ms": dec_st,
+        "encode_gnts": round(n_len / (enc_ms * 1e-3) / 1e9, 1), "decode_gnts": round(n_len / (dec_ms * 1e-3) / 1e9, 1),
+        "encode_frac": round(gbs(BYTES_PER_NT * n_len, enc_ms) / HBM_PEAK_GBS, 4),
+        "decode_frac": round(gbs(BYTES_PER_NT * n_len, dec_ms) / HBM_PEAK_GBS, 4),
+        "encode_read_view_frac": round(gbs(n_len, enc_ms) / HBM_PEAK_GBS, 4),
+        "fused_ms_median": fused["median"] if fused else None,
+        "configs4_shard": shard,
+    })
+    rows = [row]
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, row)
 
     if rank == 0:
         nt_per_step = 2 * n_global  # N encoded + N decoded, all ranks
         value = nt_per_step * args.steps / elapsed / 1e9
-        enc_gbs = BYTES_PER_NT * n_len / (enc_ms * 1e-3) / 1e9
-        dec_gbs = BYTES_PER_NT * n_len / (dec_ms * 1e-3) / 1e9
-        traffic = None
+        enc_gbs = gbs(BYTES_PER_NT * n_len, enc_ms)
+        dec_gbs = gbs(BYTES_PER_NT * n_len, dec_ms)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and args.log2_nt == 34:
             try:
                 traffic = json.load(open(tpath))
+                traffic_source = ("static: profiles/hbm_traffic.json, from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                  "calibrated; bench/profile.sh) -- NOT measured by this run; kernels recorded there: %s" %
+                                  (traffic.get("source"), traffic.get("kernels", "the shipped defaults of that round")))
             except Exception:
                 traffic = None
+        span = lambda key: {"min": min(r[key] for r in rows), "max": max(r[key] for r in rows)}
+        uuids = {r.get("uuid") or r["pci_bus_id"] for r in rows}
         line = {
             "metric": "Gnt/s encode+decode on 16 GiB random ACGT; % HBM read roofline at 1/8 GPU",
             "value": round(value, 3), "unit": "Gnt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -315,7 +570,7 @@ def main():
                 "workload": "n_to_bits encode + bits_to_n decode of a device-resident uniform random ACGT buffer, "
                             "%.3g GiB (2^%d nt) per GPU" % (n_per / 2**30, args.log2_nt),
                 "nt_per_gpu": n_per, "nt_per_step": nt_per_step, "seed": hex(args.seed),
-                "sharding": ("contiguous chunks on word boundaries, no data-path collective; control plane: " + backend)
+                "sharding": ("contiguous chunks on word boundaries (cnt_shard_range), no data-path collective; control plane: " + backend)
                 if world > 1 else "single GPU",
                 "encode_kernel": dict(devutil.variants("encode"))[devutil.get_tuning("encode")],
                 "decode_kernel": dict(devutil.variants("decode"))[devutil.get_tuning("decode")],
@@ -328,29 +583,85 @@ def main():
             "roofline": {
                 "kernel": "n_to_bits (encode)", "bound": "hbm", "achieved": round(enc_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(enc_gbs / HBM_PEAK_GBS, 4),
-                "traffic": (traffic or {}).get("encode_bytes_per_launch"),
-                "avg_kernel_ms": round(enc_ms, 4), "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
-                "read_only_view": {"achieved": round(n_len / (enc_ms * 1e-3) / 1e9, 1),
-                                   "frac": round(n_len / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "traffic": (traffic or {}).get("encode_bytes_per_launch"), "traffic_source": traffic_source,
+                "avg_kernel_ms": round(enc_ms, 4), "kernel_ms": enc_st, "frac_at_median": round(gbs(BYTES_PER_NT * n_len, enc_st["median"]) / HBM_PEAK_GBS, 4),
+                "frac_at_min": round(gbs(BYTES_PER_NT * n_len, enc_st["min"]) / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
+                "read_only_view": {"achieved": round(gbs(n_len, enc_ms), 1), "frac": round(gbs(n_len, enc_ms) / HBM_PEAK_GBS, 4)},
             },
             "roofline_decode": {
                 "kernel": "bits_to_n (decode)", "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
-                "traffic": (traffic or {}).get("decode_bytes_per_launch"),
-                "avg_kernel_ms": round(dec_ms, 4), "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
+                "traffic": (traffic or {}).get("decode_bytes_per_launch"), "traffic_source": traffic_source,
+                "avg_kernel_ms": round(dec_ms, 4), "kernel_ms": dec_st, "frac_at_median": round(gbs(BYTES_PER_NT * n_len, dec_st["median"]) / HBM_PEAK_GBS, 4),
+                "frac_at_min": round(gbs(BYTES_PER_NT * n_len, dec_st["min"]) / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
             },
+            "roofline_over_ranks": {"encode_frac": span("encode_frac"), "decode_frac": span("decode_frac"),
+                                    "encode_read_view_frac": span("encode_read_view_frac")},
+            "ranks": rows,
+            "devices": {"distinct": len(uuids), "shared_gpu_test_hook": shared_gpu,
+                        "data_path_collective": None, "control_plane": backend if world > 1 else None},
             "verified": verified,
             "value_definition": "nucleotides converted per second over all ranks: each step encodes nt_per_gpu and decodes "
                                 "nt_per_gpu on every rank (nt_per_step = 2 x n_gpus x nt_per_gpu); equals the harmonic mean "
                                 "of the encode and decode rates",
         }
-        if fused_ms is not None:
-            fgbs = 2.25 * n_len / (fused_ms * 1e-3) / 1e9
+        if fused is not None:
+            fgbs = gbs(2.25 * n_len, fused["median"])
             line["fused_round_trip"] = {
                 "what": "cnt_round_trip_dev: one pass reads the ASCII and writes packed words + decoded ASCII "
-                        "(BASELINE.json configs[3]); measured after the timed region, not part of value",
-                "ms": round(fused_ms, 4), "nt_converted_gnts": round(2 * n_len / (fused_ms * 1e-3) / 1e9, 3),
+                        "(BASELINE.json configs[3] at the metric size; its own 64 GiB size is in `configs`); measured after the "
+                        "timed region, not part of value",
+                "ms": fused["median"], "ms_stats": fused, "nt_converted_gnts": round(2 * n_len / (fused["median"] * 1e-3) / 1e9, 3),
                 "bytes_per_nt": 2.25, "achieved": round(fgbs, 1), "unit": "GB/s", "frac": round(fgbs / HBM_PEAK_GBS, 4),
+            }
+        if ceilings is not None:
+            line["ceilings"] = {
+                "what": "no-arithmetic streams issued exactly like the shipped kernels (bench/probes.hip probe_shipped), same process, "
+                        "same buffers, 2^%d-byte wide side, median of 5 launches each; GB/s of all bytes moved" % args.log2_nt,
+                "rank0": ceilings,
+            }
+            if "error" not in ceilings:
+                c = ceilings
+                line["ceilings"]["encode_vs"] = {
+                    "total_traffic_view_GBs": round(enc_gbs, 1),
+                    "of_spec_8000": round(enc_gbs / HBM_PEAK_GBS, 4),
+                    "of_read4_write1_ceiling": round(enc_gbs / c["read4_write1_encode_shape"]["GBs"], 4),
+                    "of_copy_1to1_ceiling": round(enc_gbs / c["copy_1to1"]["GBs"], 4),
+                    "of_read_only_ceiling": round(enc_gbs / c["read_only"]["GBs"], 4),
+                    "read_only_view_GBs": round(gbs(n_len, enc_ms), 1),
+                    "read_only_view_of_spec_8000": round(gbs(n_len, enc_ms) / HBM_PEAK_GBS, 4),
+                    "read_only_view_of_read_only_ceiling": round(gbs(n_len, enc_ms) / c["read_only"]["GBs"], 4),
+                }
+                line["ceilings"]["decode_vs"] = {
+                    "total_traffic_view_GBs": round(dec_gbs, 1),
+                    "of_spec_8000": round(dec_gbs / HBM_PEAK_GBS, 4),
+                    "of_read1_write4_ceiling": round(dec_gbs / c["read1_write4_decode_shape"]["GBs"], 4),
+                    "of_copy_1to1_ceiling": round(dec_gbs / c["copy_1to1"]["GBs"], 4),
+                    "of_write_only_ceiling": round(dec_gbs / c["write_only"]["GBs"], 4),
+                }
+        if configs:
+            line["configs"] = configs
+        if any(r.get("configs4_shard") and "encode_ms" in r["configs4_shard"] for r in rows):
+            sh = [r["configs4_shard"] for r in rows if r.get("configs4_shard") and "encode_ms" in r["configs4_shard"]]
+            slow = max(s["encode_ms"]["median"] for s in sh)
+            tot = sum(s["nt"] for s in sh)
+            line["configs4_sharded_encode"] = {
+                "what": "BASELINE.json configs[4]: n_to_bits encode of this run's share of '256 GiB over 8 GPUs' -- a 2^%d-nt (%.0f GiB) "
+                        "contiguous chunk per GPU (cnt_shard_range), every rank at once, no collective; at N = 8 the whole 256 GiB"
+                        % (args.shard_log2_nt, 2**args.shard_log2_nt / 2**30),
+                "nt_per_gpu": sh[0]["nt"], "total_GiB": round(tot / 2**30, 1), "ranks_measured": len(sh),
+                "per_gpu_gnts": {"min": round(min(s["nt"] / (s["encode_ms"]["median"] * 1e-3) / 1e9 for s in sh), 1),
+                                 "max": round(max(s["nt"] / (s["encode_ms"]["median"] * 1e-3) / 1e9 for s in sh), 1)},
+                "aggregate_gnts": round(tot / (sh[0]["wall_ms_per_encode_all_ranks"] * 1e-3) / 1e9, 1),
+                "aggregate_definition": "all ranks' nucleotides / wall time per encode between two barriers (max over ranks), 8 "
+                                        "back-to-back encodes per rank; per-GPU figures from each rank's own HIP events",
+                "aggregate_gnts_from_slowest_rank_events": round(tot / (slow * 1e-3) / 1e9, 1),
+                "per_gpu_frac": {"min": round(min(gbs(BYTES_PER_NT * s["nt"], s["encode_ms"]["median"]) for s in sh) / HBM_PEAK_GBS, 4),
+                                 "max": round(max(gbs(BYTES_PER_NT * s["nt"], s["encode_ms"]["median"]) for s in sh) / HBM_PEAK_GBS, 4)},
+                "per_gpu_read_view_frac": {"min": round(min(gbs(s["nt"], s["encode_ms"]["median"]) for s in sh) / HBM_PEAK_GBS, 4),
+                                           "max": round(max(gbs(s["nt"], s["encode_ms"]["median"]) for s in sh) / HBM_PEAK_GBS, 4)},
             }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -6,10 +6,19 @@
 //   kind 2  read 4 : write 1   (encode's ratio, 16-B accesses both sides)
 //   kind 3  read 1 : write 4   (decode's ratio)
 //   kind 4  write-only
+//
+// probe_shipped(): the same five streams issued EXACTLY like the shipped codec kernels (raw buffer
+// loads/stores with their cache-policy bits, the small one-shot workgroups, the XCD tile maps and the
+// residency caps of codec2_launch.hpp) -- the best no-arithmetic shapes bench/tune_lab3.hip found.
+// bench.py runs them in the same process as the headline so that the bench line carries same-run,
+// same-box ceilings: read-only, write-only, 1:1 copy, 4:1 (encode's mix), 1:4 (decode's).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#include "../cute_nucleotides_amd/csrc/codec2_kernels.hpp"
+#include "../cute_nucleotides_amd/csrc/codec2_launch.hpp"
+
+using cnt::u32x4;
 constexpr int kBlock = 256;
 
 template <bool NT> __device__ __forceinline__ u32x4 ld(const u32x4* p) {
@@ -109,6 +118,95 @@ extern "C" int probe_run(int kind, int unroll, int nt, const void* a, void* b, s
         case 2: BY_U(k_r4w1, 4, pa, pb); break;
         case 3: BY_U(k_r1w4, 4, pa, pb); break;
         case 4: BY_U(k_write, 1, pb); break;
+        default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// ---- shipped-shape probes -------------------------------------------------------------------
+namespace shipped {
+using namespace cnt;
+
+template <int BLOCK, int U, int LAUX>
+__global__ __launch_bounds__(BLOCK) void k_read(const uint8_t* __restrict__ in, uint8_t* __restrict__ sink, uint64_t n_tiles) {
+    constexpr uint32_t TILE = BLOCK * U * 16;
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + (uint64_t)blockIdx.x * TILE, TILE);
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + threadIdx.x) * 16, 0, LAUX));
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) reinterpret_cast<u32x4*>(sink)[threadIdx.x] = acc;  // practically never
+    touch_residency_pad(n_tiles, acc.x);
+}
+template <int BLOCK, int U, int SAUX>
+__global__ __launch_bounds__(BLOCK) void k_write(uint8_t* __restrict__ out, uint64_t n_tiles) {
+    constexpr uint32_t TILE = BLOCK * U * 16;
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + (uint64_t)blockIdx.x * TILE, TILE);
+    const u32x4 v = {(uint32_t)blockIdx.x, threadIdx.x, 3u, 4u};
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, v), rout, (u * BLOCK + threadIdx.x) * 16, 0, SAUX);
+    touch_residency_pad(n_tiles, v.x);
+}
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void k_copy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    constexpr uint32_t TILE = BLOCK * U * 16;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE, TILE), rout = rsrc_of(out + t * TILE, TILE);
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + threadIdx.x) * 16, 0, LAUX));
+    touch_residency_pad(n_tiles, v[0].x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, v[u]), rout, (u * BLOCK + threadIdx.x) * 16, 0, SAUX);
+}
+// encode's access shape without the arithmetic: 16 B in, 4 B out per lane and load
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void k_r4w1(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN), rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + threadIdx.x) * 16, 0, LAUX));
+    touch_residency_pad(n_tiles, v[0].x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b32(v[u].x ^ v[u].y ^ v[u].z ^ v[u].w, rout, (u * BLOCK + threadIdx.x) * 4, 0, SAUX);
+}
+// decode's access shape without the arithmetic: 4 B in, 16 B out
+template <int BLOCK, int U, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(BLOCK) void k_r1w4(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN), rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    uint32_t x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (u * BLOCK + threadIdx.x) * 4, 0, LAUX);
+    touch_residency_pad(n_tiles, x[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u32x4 v = {x[u], x[u] + 1, x[u] + 2, x[u] + 3};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, v), rout, (u * BLOCK + threadIdx.x) * 16, 0, SAUX);
+    }
+}
+}  // namespace shipped
+
+// kind 0 read-only (1024 thr x 1 load, nt) | 1 copy 1:1 (256 thr x 1, ld=nt st=sc0|sc1|nt) |
+// 2 read 4 : write 1 = n_to_bits_stream's shape, map, policies and residency cap | 3 read 1 : write 4 =
+// bits_to_n_stream's | 4 write-only (256 thr x 1 store, sc0|sc1|nt).  `bytes` = the 16-B-per-lane side
+// (kinds 0, 1, 4: the buffer; 2: bytes read from a, bytes/4 written to b; 3: bytes written to b, bytes/4
+// read from a); must be a multiple of 16 KiB and at most 2^35.  Returns 0 / 1 (bad argument) / 2 (launch).
+extern "C" int probe_shipped(int kind, const void* a, void* b, size_t bytes, void* stream) {
+    using namespace cnt;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint8_t* pa = static_cast<const uint8_t*>(a);
+    uint8_t* pb = static_cast<uint8_t*>(b);
+    if (bytes == 0 || (bytes & 16383) || bytes > ((size_t)1 << 35)) return 1;
+    constexpr int kAll = kSC0 | kSC1 | kNT;
+    switch (kind) {
+        case 0: { const uint64_t t = bytes / (1024 * 16); hipLaunchKernelGGL((shipped::k_read<1024, 1, kNT>), dim3((unsigned)t), dim3(1024), 0, s, pa, pb, t); break; }
+        case 1: { const uint64_t t = bytes / (256 * 16); hipLaunchKernelGGL((shipped::k_copy<256, 1, 1, kNT, kAll>), dim3((unsigned)t), dim3(256), 0, s, pa, pb, t); break; }
+        case 2: { const uint64_t t = bytes / (64 * 2 * 16); hipLaunchKernelGGL((shipped::k_r4w1<64, 2, 2, kNT, kAll>), dim3((unsigned)t), dim3(64), lds_for_cap(23), s, pa, pb, t); break; }
+        case 3: { const uint64_t t = bytes / (128 * 2 * 16); hipLaunchKernelGGL((shipped::k_r1w4<128, 2, 4, 0, kAll>), dim3((unsigned)t), dim3(128), lds_for_cap(13), s, pa, pb, t); break; }
+        case 4: { const uint64_t t = bytes / (256 * 16); hipLaunchKernelGGL((shipped::k_write<256, 1, kAll>), dim3((unsigned)t), dim3(256), 0, s, pb, t); break; }
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -23,6 +23,8 @@ SIGNATURES = {
     "cnt_device_count": (_int, [ctypes.POINTER(_int)]),
     "cnt_set_device": (_int, [_int]),
     "cnt_get_device": (_int, [ctypes.POINTER(_int)]),
+    "cnt_device_pci_bus_id": (_int, [_int, ctypes.c_char_p, _sz]),
+    "cnt_device_numa_node": (_int, [_int, ctypes.POINTER(_int)]),
     "cnt_shutdown": (_int, []),
     "cnt_n_to_bits": (_int, [_vp, _sz, _vp, _sz]),
     "cnt_n_to_bits_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
@@ -44,6 +46,11 @@ SIGNATURES = {
     "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
     "cnt_round_trip_dev": (_int, [_vp, _sz, _vp, _sz, _vp, _uint, _vp]),
     "cnt_bits_to_n2_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
+    "cnt_dev_alloc": (_int, [ctypes.POINTER(_vp), _sz]),
+    "cnt_dev_free": (_int, [_vp]),
+    "cnt_dev_upload": (_int, [_vp, _vp, _sz]),
+    "cnt_dev_download": (_int, [_vp, _vp, _sz]),
+    "cnt_dev_sync": (_int, [_vp]),
     "cnt_fill_random_acgt_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),
     "cnt_fill_random_acgtn_dev": (_int, [_vp, _sz, _sz, _u64, _vp]),
     "cnt_checksum_words_dev": (_int, [_vp, _sz, _sz, _vp, _vp]),

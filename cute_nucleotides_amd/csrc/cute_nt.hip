@@ -989,6 +989,25 @@ int cnt_get_device(int* device) {
     return hip_rc(hipGetDevice(device));
 }
 
+// identity / placement of a device, for multi-GPU reports and for callers that pin their own threads
+int cnt_device_pci_bus_id(int device, char* buf, size_t cap) {
+    if (!buf || cap < 13) return CNT_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CNT_ENODEV;
+    return hip_rc(hipDeviceGetPCIBusId(buf, (int)std::min<size_t>(cap, 64), device));
+}
+
+int cnt_device_numa_node(int device, int* node) {
+    if (!node) return CNT_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CNT_ENODEV;
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &all);
+    *node = numa_of_device(device, all).node;
+    return CNT_OK;
+}
+
 static int release_thread_ctx() {
     t_ctx.pool.stop();
     for (auto& kv : t_ctx.per_device) kv.second.release();
@@ -1096,6 +1115,26 @@ int cnt_n_to_bits2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_wo
 int cnt_bits_to_n2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, void* stream) {
     return decode2_dev(d_bits, words, len, d_out, flags, static_cast<hipStream_t>(stream));
 }
+
+// ---- device memory for callers that do not link HIP themselves (Rust / C / C++ benches) ----------
+int cnt_dev_alloc(void** d_ptr, size_t bytes) {
+    if (!d_ptr) return CNT_EINVAL;
+    *d_ptr = nullptr;
+    if (bytes == 0) return CNT_OK;
+    return hip_rc(hipMalloc(d_ptr, bytes));
+}
+int cnt_dev_free(void* d_ptr) { return d_ptr ? hip_rc(hipFree(d_ptr)) : CNT_OK; }
+int cnt_dev_upload(void* d_dst, const void* h_src, size_t bytes) {
+    if (bytes == 0) return CNT_OK;
+    if (!d_dst || !h_src) return CNT_EINVAL;
+    return hip_rc(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+}
+int cnt_dev_download(void* h_dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return CNT_OK;
+    if (!h_dst || !d_src) return CNT_EINVAL;
+    return hip_rc(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+}
+int cnt_dev_sync(void* stream) { return hip_rc(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
 
 // ---- utilities ----------------------------------------------------------------------
 int cnt_fill_random_acgt_dev(void* d_out, size_t first_nt, size_t n_len, uint64_t seed, void* stream) {

@@ -83,22 +83,53 @@ def bits_to_n_hip_sharded(bits, length, ndev=0):
 
 
 # ---- device tier (torch tensors; torch is plumbing for device memory + streams) -----------
-def _stream_ptr():
-    import torch
-
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
 def _dev_guard(t):
     import torch
 
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("device tier needs a contiguous CUDA tensor")
-    cur = ctypes.c_int(-1)
-    check(lib().cnt_get_device(ctypes.byref(cur)))
-    if cur.value != t.device.index:
-        check(lib().cnt_set_device(t.device.index))
     return torch
+
+
+def _enqueue(t, fn, *args):
+    """Call a device-tier entry point for tensor `t`: on t's device, on torch's current stream OF THAT
+    DEVICE (appended as the last argument), and with the calling thread's HIP device left exactly as it
+    was found -- a codec call on a cuda:1 tensor must not move the process to cuda:1."""
+    import torch
+
+    L = lib()
+    cur = ctypes.c_int(-1)
+    check(L.cnt_get_device(ctypes.byref(cur)))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if cur.value == t.device.index:
+        check(fn(*args, stream))
+        return
+    check(L.cnt_set_device(t.device.index))
+    try:
+        rc = fn(*args, stream)
+    finally:
+        L.cnt_set_device(cur.value)
+    check(rc)
+
+
+def _out_words(torch, out, words, like):
+    """a caller-supplied word buffer: int64, contiguous, on the input's device, >= `words` elements -- the C ABI
+    counts capacity in WORDS, so anything narrower than 8 bytes per element would be written out of bounds"""
+    if out is None:
+        return torch.empty(words, dtype=torch.int64, device=like.device)
+    if out.dtype != torch.int64 or not out.is_cuda or not out.is_contiguous() or out.device != like.device or out.numel() < words:
+        raise ValueError("out must be a contiguous int64 CUDA tensor on the input's device with >= %d elements" % words)
+    return out
+
+
+def _out_bytes(torch, out, length, like):
+    """a caller-supplied ASCII buffer: uint8, contiguous, on the input's device, >= `length` elements (the decode
+    entry points of the C ABI take no output capacity: this check is the only one there is)"""
+    if out is None:
+        return torch.empty(length, dtype=torch.uint8, device=like.device)
+    if out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous() or out.device != like.device or out.numel() < length:
+        raise ValueError("out must be a contiguous uint8 CUDA tensor on the input's device with >= %d elements" % length)
+    return out
 
 
 def words_for(n_len):
@@ -112,12 +143,9 @@ def n_to_bits_dev(n, out=None, strict_lut=False):
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     words = lib().cnt_words_for(n.numel())
-    if out is None:
-        out = torch.empty(words, dtype=torch.int64, device=n.device)
-    elif out.dtype != torch.int64 or not out.is_cuda or not out.is_contiguous() or out.device != n.device:
-        raise ValueError("out must be a contiguous int64 CUDA tensor on the input's device")
-    check(lib().cnt_n_to_bits_dev(ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
-                                  out.numel(), CNT_STRICT_LUT if strict_lut else 0, _stream_ptr()))
+    out = _out_words(torch, out, words, n)
+    _enqueue(n, lib().cnt_n_to_bits_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
+             out.numel(), CNT_STRICT_LUT if strict_lut else 0)
     return out[:words]
 
 
@@ -128,15 +156,10 @@ def round_trip_dev(n, out_bits=None, out_n=None, strict_lut=False):
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     words = lib().cnt_words_for(n.numel())
-    if out_bits is None:
-        out_bits = torch.empty(words, dtype=torch.int64, device=n.device)
-    if out_n is None:
-        out_n = torch.empty(n.numel(), dtype=torch.uint8, device=n.device)
-    if out_bits.dtype != torch.int64 or out_n.dtype != torch.uint8 or out_n.numel() < n.numel() or not (
-            out_bits.is_cuda and out_n.is_cuda and out_bits.is_contiguous() and out_n.is_contiguous()):
-        raise ValueError("out_bits: contiguous int64 CUDA tensor; out_n: contiguous uint8 CUDA tensor with >= len(n) elements")
-    check(lib().cnt_round_trip_dev(ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out_bits.data_ptr()), out_bits.numel(),
-                                   ctypes.c_void_p(out_n.data_ptr()), CNT_STRICT_LUT if strict_lut else 0, _stream_ptr()))
+    out_bits = _out_words(torch, out_bits, words, n)
+    out_n = _out_bytes(torch, out_n, n.numel(), n)
+    _enqueue(n, lib().cnt_round_trip_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out_bits.data_ptr()),
+             out_bits.numel(), ctypes.c_void_p(out_n.data_ptr()), CNT_STRICT_LUT if strict_lut else 0)
     return out_bits[:words], out_n[: n.numel()]
 
 
@@ -147,10 +170,6 @@ def bits_to_n_dev(bits, length, out=None):
         raise TypeError("packed words must be an int64 tensor (u64 bit pattern)")
     if length > bits.numel() * 32:
         check(_lib.CNT_ELEN)
-    if out is None:
-        out = torch.empty(length, dtype=torch.uint8, device=bits.device)
-    elif out.dtype != torch.uint8 or out.numel() < length or not out.is_cuda or not out.is_contiguous():
-        raise ValueError("out must be a contiguous uint8 CUDA tensor with >= length elements")
-    check(lib().cnt_bits_to_n_dev(ctypes.c_void_p(bits.data_ptr()), bits.numel(), length,
-                                  ctypes.c_void_p(out.data_ptr()), 0, _stream_ptr()))
+    out = _out_bytes(torch, out, length, bits)
+    _enqueue(bits, lib().cnt_bits_to_n_dev, ctypes.c_void_p(bits.data_ptr()), bits.numel(), length, ctypes.c_void_p(out.data_ptr()), 0)
     return out[:length]

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CNT_STRICT_LUT, check, lib
-from .n_to_bits import _dev_guard, _p, _stream_ptr, _u8, _u64
+from .n_to_bits import _dev_guard, _enqueue, _out_bytes, _out_words, _p, _u8, _u64
 
 
 def n_to_bits2_hip(n):
@@ -55,10 +55,9 @@ def n_to_bits2_dev(n, out=None, strict_lut=False):
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     words = lib().cnt_words2_for(n.numel())
-    if out is None:
-        out = torch.empty(words, dtype=torch.int64, device=n.device)
-    check(lib().cnt_n_to_bits2_dev(ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
-                                   out.numel(), CNT_STRICT_LUT if strict_lut else 0, _stream_ptr()))
+    out = _out_words(torch, out, words, n)
+    _enqueue(n, lib().cnt_n_to_bits2_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
+             out.numel(), CNT_STRICT_LUT if strict_lut else 0)
     return out[:words]
 
 
@@ -68,8 +67,6 @@ def bits_to_n2_dev(bits, length, out=None):
         raise TypeError("packed words must be an int64 tensor (u64 bit pattern)")
     if length > bits.numel() * 27:
         check(_lib.CNT_ELEN)
-    if out is None:
-        out = torch.empty(length, dtype=torch.uint8, device=bits.device)
-    check(lib().cnt_bits_to_n2_dev(ctypes.c_void_p(bits.data_ptr()), bits.numel(), length,
-                                   ctypes.c_void_p(out.data_ptr()), 0, _stream_ptr()))
+    out = _out_bytes(torch, out, length, bits)
+    _enqueue(bits, lib().cnt_bits_to_n2_dev, ctypes.c_void_p(bits.data_ptr()), bits.numel(), length, ctypes.c_void_p(out.data_ptr()), 0)
     return out[:length]

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from ._lib import check, lib
-from .n_to_bits import _dev_guard, _p, _stream_ptr, _u8, _u64
+from .n_to_bits import _dev_guard, _enqueue, _out_words, _p, _u8, _u64
 
 CNT_ALLOW_N = 0x2
 
@@ -58,11 +58,12 @@ def hamming_dev(a, b, length):
     _dev_guard(b)
     if a.dtype != torch.int64 or b.dtype != torch.int64:
         raise TypeError("packed words must be int64 tensors")
+    if a.device != b.device:
+        raise ValueError("both sequences must live on the same device")
     if length > min(a.numel(), b.numel()) * 32:
         raise ValueError("The length is greater than the number of nucleotides!")
     acc = torch.zeros(1, dtype=torch.int64, device=a.device)
-    check(lib().cnt_hamming_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), length,
-                                ctypes.c_void_p(acc.data_ptr()), _stream_ptr()))
+    _enqueue(a, lib().cnt_hamming_dev, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), length, ctypes.c_void_p(acc.data_ptr()))
     return acc  # device scalar: .item() syncs
 
 
@@ -73,9 +74,8 @@ def _unary_dev(fn, bits, length, out):
     if length > bits.numel() * 32:
         raise ValueError("The length is greater than the number of nucleotides!")
     words = lib().cnt_words_for(length)
-    if out is None:
-        out = torch.empty(words, dtype=torch.int64, device=bits.device)
-    check(fn(ctypes.c_void_p(bits.data_ptr()), length, ctypes.c_void_p(out.data_ptr()), _stream_ptr()))
+    out = _out_words(torch, out, words, bits)
+    _enqueue(bits, fn, ctypes.c_void_p(bits.data_ptr()), length, ctypes.c_void_p(out.data_ptr()))
     return out[:words]
 
 
@@ -92,6 +92,5 @@ def validate_dev(n, allow_n=False):
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     acc = torch.zeros(1, dtype=torch.int64, device=n.device)
-    check(lib().cnt_validate_dev(ctypes.c_void_p(n.data_ptr()), n.numel(), CNT_ALLOW_N if allow_n else 0,
-                                 ctypes.c_void_p(acc.data_ptr()), _stream_ptr()))
+    _enqueue(n, lib().cnt_validate_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), CNT_ALLOW_N if allow_n else 0, ctypes.c_void_p(acc.data_ptr()))
     return acc

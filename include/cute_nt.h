@@ -74,6 +74,11 @@ size_t cnt_words2_for(size_t n_len);
 int cnt_device_count(int *count);
 int cnt_set_device(int device); /* per calling thread, like hipSetDevice */
 int cnt_get_device(int *device);
+/* Identity and placement of a visible device: its PCI address ("0000:05:00.0", cap >= 13) and the
+ * NUMA node it hangs off (/sys/bus/pci/devices/<address>/numa_node; -1 = the platform does not say).
+ * What the sharded tier pins its workers by, and what bench.py prints per rank. */
+int cnt_device_pci_bus_id(int device, char *buf, size_t cap);
+int cnt_device_numa_node(int device, int *node);
 /* Frees the calling thread's cached stream/scratch on every device it used. */
 int cnt_shutdown(void);
 
@@ -156,6 +161,16 @@ int cnt_n_to_bits2_dev(const void *d_n, size_t n_len, void *d_out, size_t out_wo
  * all three pointers 128-byte aligned; otherwise the call is the two calls above in sequence. */
 int cnt_round_trip_dev(const void *d_n, size_t n_len, void *d_bits, size_t out_words, void *d_back, unsigned flags, void *stream);
 int cnt_bits_to_n2_dev(const void *d_bits, size_t words, size_t len, void *d_out, unsigned flags, void *stream);
+
+/* Device memory for callers that do not link the HIP runtime themselves (the Rust / C++ bench rows
+ * that drive the device tier): hipMalloc / hipFree / synchronous hipMemcpy / hipStreamSynchronize on
+ * the calling thread's current device.  A caller that already owns device memory (PyTorch, its own
+ * HIP code) never needs these. */
+int cnt_dev_alloc(void **d_ptr, size_t bytes);
+int cnt_dev_free(void *d_ptr);
+int cnt_dev_upload(void *d_dst, const void *h_src, size_t bytes);
+int cnt_dev_download(void *h_dst, const void *d_src, size_t bytes);
+int cnt_dev_sync(void *stream);
 
 /* ---- packed-domain operations ----------------------------------- */
 /* The reference does not implement these; its README points at them as the reason to keep

@@ -219,3 +219,52 @@ def test_large_ragged_size_64bit_indexing(cn, oracle):
     first_word = packed.numel() - tail_words
     host = oracle.fill_random_acgtn(n_len - 27 * first_word, 31, first_nt=27 * first_word)
     assert np.array_equal(packed[first_word:].cpu().numpy().view(np.uint64), oracle.n_to_bits2_lut(host))
+
+
+def test_caller_supplied_outputs_are_validated(cn):
+    """The C ABI counts output capacity in WORDS and the decoders take no capacity at all, so the Python
+    device tier must refuse an `out` that is too narrow, too short, non-contiguous or on the host -- both
+    codecs, the fused call and the packed-domain ops (a uint8 `out` with numel == words would pass the C
+    check and be written 8x out of bounds)."""
+    import torch
+
+    from cute_nucleotides_amd import n_to_bits2 as n2
+    from cute_nucleotides_amd import packed_ops as po
+
+    n = torch.full((27 * 100,), 65, dtype=torch.uint8, device="cuda")
+    words5, words2 = 100, (27 * 100 + 31) // 32
+    ok5 = n2.n_to_bits2_dev(n, out=torch.empty(words5 + 3, dtype=torch.int64, device="cuda"))
+    assert ok5.numel() == words5
+    bad_word_outs = [torch.empty(words5, dtype=torch.uint8, device="cuda"), torch.empty(words5 - 1, dtype=torch.int64, device="cuda"),
+                     torch.empty(2 * words5, dtype=torch.int64, device="cuda")[::2], torch.empty(words5, dtype=torch.int64)]
+    for bad in bad_word_outs:
+        with pytest.raises(ValueError):
+            n2.n_to_bits2_dev(n, out=bad)
+        with pytest.raises(ValueError):
+            cn.n_to_bits_dev(n, out=bad[: words2 - 1] if (bad.is_cuda and bad.is_contiguous() and bad.dtype == torch.int64) else bad)
+    bad_byte_outs = [torch.empty(2700, dtype=torch.int8, device="cuda"), torch.empty(2699, dtype=torch.uint8, device="cuda"),
+                     torch.empty(5400, dtype=torch.uint8, device="cuda")[::2], torch.empty(2700, dtype=torch.uint8)]
+    bits2 = cn.n_to_bits_dev(n)
+    for bad in bad_byte_outs:
+        with pytest.raises(ValueError):
+            n2.bits_to_n2_dev(ok5, 2700, out=bad)
+        with pytest.raises(ValueError):
+            cn.bits_to_n_dev(bits2, 2700, out=bad)
+        with pytest.raises(ValueError):
+            cn.round_trip_dev(n, out_n=bad)
+    for bad in bad_word_outs[:1] + bad_word_outs[2:]:
+        with pytest.raises(ValueError):
+            po.complement_dev(bits2, 2700, out=bad)
+        with pytest.raises(ValueError):
+            po.reverse_complement_dev(bits2, 2700, out=bad)
+        with pytest.raises(ValueError):
+            cn.round_trip_dev(n, out_bits=bad)
+    with pytest.raises(ValueError):
+        po.complement_dev(bits2, 2700, out=torch.empty(words2 - 1, dtype=torch.int64, device="cuda"))
+    # and the calling thread's HIP device is where it was
+    assert torch.cuda.current_device() == 0
+    from cute_nucleotides_amd import _lib
+    import ctypes
+
+    cur = ctypes.c_int(-1)
+    assert _lib.lib().cnt_get_device(ctypes.byref(cur)) == 0 and cur.value == 0
