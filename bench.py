@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HOST_TIER_LOG2 = (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)  # sizes of the host-tier / one-CPU-thread crossover table
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_NT = 1.25    # algorithmic bytes per nucleotide, each direction
 
@@ -188,18 +189,21 @@ def cpu_baseline(seconds):
     # the same allocation-inclusive single-thread calls at 1 MiB and 1 GiB of random ACGT
     # (DRAM-resident at 1 GiB; every call pays the page faults of its fresh output, like a fresh Vec)
     faithful_big = {}
-    for log2 in (20, 30):
+    for log2 in HOST_TIER_LOG2:
         m = 1 << log2
         if m > n_len:
             continue
         L.cnt_port_n_to_bits_movemask(n.ctypes.data, m, bits.ctypes.data, m // 32)
         row = {}
+        every = log2 in (20, 30)  # all ten functions at the two sizes SURVEY 8d names; the fastest pair + memcpy elsewhere
         for fn, name in names.items():
+            if not every and fn not in (3, 5, 11):
+                continue
             src = n if fn < 10 else bits
-            slow = fn in (0, 10)
-            iters = (200 if not slow else 20) if log2 == 20 else (3 if not slow else 1)
-            if log2 == 20:
-                L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, m, 5)
+            est = m / (1.3e9 if fn in (0, 10) else 15e9)
+            iters = max(1, min(20000, int(0.08 / est)))
+            if log2 <= 24:
+                L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, m, max(1, iters // 10))
             per = L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, m, iters)
             row[name] = round(m / per / 2**30, 3)
         faithful_big["2^%d" % log2] = row
@@ -281,6 +285,74 @@ def measure_ceilings(torch, P, d_a, d_b, nbytes, iters=5):
         rows[name] = {"GBs": round(gbs(moved, statistics.median(ms)), 1), "best_GBs": round(gbs(moved, min(ms)), 1),
                       "bytes_moved": int(moved), "ms_median": round(statistics.median(ms), 4)}
     return rows
+
+
+def measure_host_tier(seed):
+    """The drop-in host-pointer tier (cnt_n_to_bits / cnt_bits_to_n: H2D + kernel + D2H inside, PCIe-bound) at the
+    sizes of the crossover table, timed like the reference's harness times its functions: one calling thread, the
+    output allocated inside every timed call (np.empty -> fresh pages, like a fresh Vec), and again into a reused
+    output.  GiB/s of nucleotides.  Never part of `value`."""
+    import numpy as np
+
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(seed)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 1 << HOST_TIER_LOG2[-1], dtype=np.uint8)]
+    rows = {}
+    for log2 in HOST_TIER_LOG2:
+        m = 1 << log2
+        n = big[:m]
+        words = m // 32
+        bits = np.empty(words, dtype=np.uint64)
+        back = np.empty(m, dtype=np.uint8)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+
+        def enc_fresh():
+            out = np.empty(words, dtype=np.uint64)
+            return L.cnt_n_to_bits(p(n), m, p(out), words)
+
+        def dec_fresh():
+            out = np.empty(m, dtype=np.uint8)
+            return L.cnt_bits_to_n(p(bits), words, m, p(out))
+
+        def enc_reuse():
+            return L.cnt_n_to_bits(p(n), m, p(bits), words)
+
+        def dec_reuse():
+            return L.cnt_bits_to_n(p(bits), words, m, p(back))
+
+        row = {}
+        for name, fn in (("n_to_bits_hip reused out", enc_reuse), ("bits_to_n_hip reused out", dec_reuse),
+                         ("n_to_bits_hip fresh out", enc_fresh), ("bits_to_n_hip fresh out", dec_fresh)):
+            assert fn() == 0
+            t0, k = time.perf_counter(), 0
+            while True:
+                fn()
+                k += 1
+                dt = time.perf_counter() - t0
+                if dt > 0.12 or k >= 20000:
+                    break
+            row[name] = round(m / (dt / k) / 2**30, 3)
+            row[name + " us"] = round(dt / k * 1e6, 2)
+        assert np.array_equal(back, n)
+        rows["2^%d" % log2] = row
+    return rows
+
+
+def crossover(host_rows, cpu_rows):
+    """smallest table size from which the host tier stays ahead of ONE CPU thread running the reference's fastest
+    AVX2 path, both allocating their output inside the call (the reference's bench rule)"""
+    out = {}
+    for gpu_key, cpu_key in (("n_to_bits_hip fresh out", "n_to_bits_movemask"), ("bits_to_n_hip fresh out", "bits_to_n_shuffle")):
+        sizes = [k for k in host_rows if k in cpu_rows and cpu_key in cpu_rows[k]]
+        ahead = [host_rows[k][gpu_key] > cpu_rows[k][cpu_key] for k in sizes]
+        first = next((sizes[i] for i in range(len(sizes)) if all(ahead[i:])), None)
+        out[gpu_key.split()[0] + " vs " + cpu_key] = {
+            "host_tier_ahead_from": first,
+            "table_GiBs": {k: [host_rows[k][gpu_key], cpu_rows[k][cpu_key]] for k in sizes},
+            "columns": ["host tier (PCIe inside)", "one CPU thread, " + cpu_key]}
+    return out
 
 
 def main():
@@ -665,6 +737,13 @@ def main():
             }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            if extras:
+                line["host_tier"] = {
+                    "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread, "
+                            "GiB/s of nucleotides; `fresh out` allocates the output inside the timed call like the reference's functions do",
+                    "rows": measure_host_tier(args.seed)}
+                cpu_rows = line["cpu_baseline"].get("reference_faithful_GiBs_1thread_alloc_inclusive") or {}
+                line["host_tier"]["crossover_vs_one_cpu_thread"] = crossover(line["host_tier"]["rows"], cpu_rows)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -10,6 +10,11 @@
 //   hipcc -O2 -std=c++17 -o bench/bench_n_to_bits bench/bench_n_to_bits.cpp \
 //         -Lcute_nucleotides_amd -lcute_nt_hip -Wl,-rpath,'$ORIGIN/../cute_nucleotides_amd'
 //
+// Device-resident rows (`*_hip_dev`: the input already in HBM, enqueue + sync per call) show what is
+// left when PCIe and the fresh-vector page faults are taken away -- the tier bench.py's roofline
+// numbers measure.  rust/benches/bench_n_to_bits.rs is the same harness in the reference's own
+// language (std-only, uncompiled here: no Rust toolchain in the image).
+//
 // The CPU rows of the reference's table (n_to_bits_lut, _pext, ... on the host cores) are
 // produced by bench.py's cpu_baseline leg, which is the only bench allowed to call oracle/.
 #include <chrono>
@@ -70,6 +75,27 @@ int main(int argc, char** argv) {
         });
         const auto bits = n_to_bits::n_to_bits_hip(n);  // get_bits(10000), :76-78
         bench_function("bits_to_n", "bits_to_n_hip", 40000, [&] { g_sink += n_to_bits::bits_to_n_hip(bits, 40000).back(); });
+        // the same 40 000 nucleotides resident in HBM: one enqueue + one stream sync per call
+        void *d_n = nullptr, *d_bits = nullptr, *d_back = nullptr;
+        if (cnt_dev_alloc(&d_n, 40000) || cnt_dev_alloc(&d_bits, 1250 * 8) || cnt_dev_alloc(&d_back, 40000) ||
+            cnt_dev_upload(d_n, n.data(), 40000)) {
+            fprintf(stderr, "device allocation failed\n");
+            return 1;
+        }
+        bench_function("n_to_bits", "n_to_bits_hip_dev (resident)", 40000, [&] {
+            g_sink += (uint64_t)cnt_n_to_bits_dev(d_n, 40000, d_bits, 1250, 0, nullptr) + (uint64_t)cnt_dev_sync(nullptr);
+        });
+        bench_function("bits_to_n", "bits_to_n_hip_dev (resident)", 40000, [&] {
+            g_sink += (uint64_t)cnt_bits_to_n_dev(d_bits, 1250, 40000, d_back, 0, nullptr) + (uint64_t)cnt_dev_sync(nullptr);
+        });
+        std::vector<uint64_t> chk(1250);
+        std::vector<uint8_t> back(40000);
+        if (cnt_dev_download(chk.data(), d_bits, 1250 * 8) || cnt_dev_download(back.data(), d_back, 40000) || chk != bits || back != n ||
+            chk[0] != 0xD8D8D8D8D8D8D8D8ull) {  // the reference's unit-test vector, n_to_bits.rs:414-415
+            fprintf(stderr, "device-tier mismatch at 40000 nt\n");
+            return 2;
+        }
+        cnt_dev_free(d_n); cnt_dev_free(d_bits); cnt_dev_free(d_back);
     }
     {
         const auto n = repeat("ATCGN", 8000);  // get_nucleotides_undetermined(8000), :72-74
@@ -109,7 +135,23 @@ int main(int argc, char** argv) {
             fprintf(stderr, "round trip mismatch at 2^%zu\n", log2);
             return 2;
         }
+        // resident rows at the same size
+        void *d_n = nullptr, *d_bits = nullptr, *d_back = nullptr;
+        if (cnt_dev_alloc(&d_n, len) || cnt_dev_alloc(&d_bits, bits.size() * 8) || cnt_dev_alloc(&d_back, len) || cnt_dev_upload(d_n, n.data(), len)) {
+            fprintf(stderr, "device allocation failed at 2^%zu\n", log2);
+            return 1;
+        }
+        snprintf(nm, sizeof nm, "n_to_bits_hip_dev/2^%zu (resident)", log2);
+        bench_function("device-tier", nm, len, [&] { g_sink += (uint64_t)cnt_n_to_bits_dev(d_n, len, d_bits, bits.size(), 0, nullptr) + (uint64_t)cnt_dev_sync(nullptr); });
+        snprintf(nm, sizeof nm, "bits_to_n_hip_dev/2^%zu (resident)", log2);
+        bench_function("device-tier", nm, len, [&] { g_sink += (uint64_t)cnt_bits_to_n_dev(d_bits, bits.size(), len, d_back, 0, nullptr) + (uint64_t)cnt_dev_sync(nullptr); });
+        if (cnt_dev_download(bits_out.data(), d_bits, bits.size() * 8) || cnt_dev_download(n_out.data(), d_back, len) || bits_out != bits || n_out != n) {
+            fprintf(stderr, "device-tier mismatch at 2^%zu\n", log2);
+            return 2;
+        }
+        cnt_dev_free(d_n); cnt_dev_free(d_bits); cnt_dev_free(d_back);
     }
     cnt_shutdown();
+    printf("self-check ok: every C-ABI row reproduced its input (host tier, reused outputs, device tier)\n");
     return 0;
 }

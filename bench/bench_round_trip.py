@@ -15,7 +15,8 @@ from cute_nucleotides_amd import devutil  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)
-ap.add_argument("--caps", default="16")
+ap.add_argument("--caps", default="8")
+ap.add_argument("--shapes", default="0", help="comma list of round_trip_shape values (0 = default, 1 = first shipped shape)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=4)
 a = ap.parse_args()
@@ -43,14 +44,16 @@ def two_pass():
 
 two_pass()
 ref = devutil.checksum_words(d_pk)
-cases = [("two passes (n_to_bits_dev + bits_to_n_dev)", None, 2.5)] + [("fused round trip, %s wg/CU" % (c or "uncapped"), int(c), 2.25) for c in a.caps.split(",")]
+cases = [("two passes (n_to_bits_dev + bits_to_n_dev)", None, 2.5)] + [
+    ("fused round trip, shape %s, %s wg/CU" % (sh, c or "uncapped"), (int(sh), int(c)), 2.25) for sh in a.shapes.split(",") for c in a.caps.split(",")]
 times = {c[0]: [] for c in cases}
 for r in range(a.rounds + 1):
     for name, cap, _ in cases:
         if cap is None:
             t = timed(two_pass)
         else:
-            devutil.set_tuning("round_trip_cap", cap)
+            devutil.set_tuning("round_trip_shape", cap[0])
+            devutil.set_tuning("round_trip_cap", cap[1])
             d_pk.zero_()
             t = timed(lambda: cn.round_trip_dev(d_in, out_bits=d_pk, out_n=d_out))
             assert devutil.checksum_words(d_pk) == ref and devutil.count_mismatch(d_in, d_out) == 0

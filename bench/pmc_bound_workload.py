@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Workload for bench/pmc_bound.sh: the shipped-shape no-arithmetic streams (bench/probes.hip probe_shipped:
+read-only, write-only, 1:1 copy, 4:1 = encode's shape, 1:4 = decode's shape) and the three codec kernels
+(encode, decode, fused round trip), each launched `reps` times over the same 2^34-nt buffers, so that one
+rocprofv3 --pmc pass sees the L2<->fabric request counters of all of them side by side."""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import cute_nucleotides_amd as cn  # noqa: E402
+from cute_nucleotides_amd import devutil  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log2-nt", type=int, default=34)
+ap.add_argument("--reps", type=int, default=4)
+a = ap.parse_args()
+n = 1 << a.log2_nt
+d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
+d_packed = torch.empty(n // 32, dtype=torch.int64, device="cuda")
+d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+devutil.fill_random_acgt(d_in, 0x5EED)
+P = ctypes.CDLL(os.path.join(ROOT, "bench", "libcnt_probes.so"))
+P.probe_shipped.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for _ in range(a.reps):
+    for kind in (0, 4, 1, 2, 3):
+        assert P.probe_shipped(kind, d_in.data_ptr(), d_out.data_ptr(), n, s) == 0
+    cn.n_to_bits_dev(d_in, out=d_packed)
+    cn.bits_to_n_dev(d_packed, n, out=d_out)
+    cn.round_trip_dev(d_in, out_bits=d_packed, out_n=d_out)
+torch.cuda.synchronize()
+assert devutil.count_mismatch(d_in, d_out) == 0
+print("pmc bound workload ok: n = 2^%d, reps = %d" % (a.log2_nt, a.reps))

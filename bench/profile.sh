@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench --
     python "$REPO/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 --no-verify --no-extras > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_fused36" -o fused36 -- \
-    python "$REPO/bench/bench_round_trip.py" --log2-nt 36 --caps 13 --rounds 3 --iters 2 > "$OUT/fused36_under_rocprof.jsonl" 2> "$OUT/stats_fused36.err"
+    python "$REPO/bench/bench_round_trip.py" --log2-nt 36 --caps 8 --rounds 3 --iters 2 > "$OUT/fused36_under_rocprof.jsonl" 2> "$OUT/stats_fused36.err"
 echo "stats fused36 rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- \
     python "$REPO/bench/pmc_workload.py" > "$OUT/pmc_fetch.log" 2>&1

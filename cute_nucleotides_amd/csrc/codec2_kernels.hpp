@@ -90,7 +90,12 @@ __device__ __forceinline__ uint64_t tile_of_block(uint64_t b, uint64_t n_tiles) 
 // Bits 1..2 of each byte are the code (n_to_bits.rs:85 mask 0x06).  With
 // y = x & 0x06060606 the four codes sit at bits {1,2},{9,10},{17,18},{25,26};
 // OR-ing y, y<<6, y<<12, y<<18 lines them up at bits 19..26 (checked
-// exhaustively in tests/test_bit_tricks.py); two v_lshl_or_b32 build it.
+// exhaustively in tests/test_bit_tricks.py).  The source spells it as two shift-ORs; because the
+// shifted copies never overlap, OR == ADD and hipcc -O3 emits ONE v_mul_lo_u32 by 0x41041 (0x820820
+// for the dword whose byte is wanted at bits 24..31) -- the reference's n_to_bits_mul identity
+// (n_to_bits.rs:223-231) found by the compiler.  Quarter-rate, 8 per lane and tile, and free: forcing
+// the two full-rate v_lshl_or_b32 with inline asm, or removing the arithmetic altogether, moves the
+// kernel by < 0.3 % (bench/tune_lab12.hip, profiles/r02_tune_lab12_encode_arithmetic.log).
 __device__ __forceinline__ uint32_t enc_gather(uint32_t y) {
     uint32_t u = (y << 6) | y;
     return (u << 12) | u;  // packed byte at bits 19..26
@@ -221,9 +226,10 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
 }
 
 // FUSED round trip (BASELINE.json configs[3]): one pass that reads the ASCII once and writes BOTH the
-// packed words and the decoded (canonical: upper case, U -> T) ASCII -- encode's tile shape, the
-// packed dword a lane just built is decoded from registers, so the packed form is never read back:
-// 1 + 0.25 + 1 = 2.25 B/nt instead of the 2.5 B/nt of encode followed by decode.
+// packed words and the decoded (canonical: upper case, U -> T) ASCII -- the packed dword a lane just
+// built is decoded from registers, so the packed form is never read back: 1 + 0.25 + 1 = 2.25 B/nt
+// instead of the 2.5 B/nt of encode followed by decode.  Launched as <64, 4, 1>: one wave, four loads
+// per lane, 4 KiB of ASCII per workgroup, plain dispatch order (codec2_launch.hpp, bench/tune_lab11.hip).
 template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed,
                                                            uint8_t* __restrict__ back, uint64_t n_tiles) {

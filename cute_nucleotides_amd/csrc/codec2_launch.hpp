@@ -103,17 +103,31 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
     }
 }
 
-// Fused round trip: whole 2-KiB tiles only; all three pointers 128-B aligned.  `cap` = resident
-// one-wave workgroups per CU (0 = uncapped).
-constexpr uint32_t kRoundTripTile = 64 * 2 * 16;
+// Fused round trip: whole 4-KiB tiles only; all three pointers 128-B aligned.  `cap` = resident
+// one-wave workgroups per CU (0 = uncapped).  Shape from its own sweep (bench/tune_lab11.hip,
+// profiles/r02_tune_lab11_*.log): one wave, FOUR 16-B loads per lane (4 KiB of ASCII in, 1 KiB of
+// words + 4 KiB of ASCII out per workgroup), plain dispatch order (no XCD regrouping) and 8 resident
+// workgroups per CU (72 KiB in flight per CU): 5.63-5.65 ms at 2^34 nt against 5.81-5.90 ms for
+// encode's shape (two loads, XCD pairs, cap 13) that the kernel first shipped with.  Its traffic is
+// 1 B read : 1.25 B written -- decode's mix, not encode's -- and like decode it wants whole 4-KiB
+// pieces of the WIDE streams per workgroup.
+constexpr uint32_t kRoundTripTile = 64 * 4 * 16;
+constexpr uint32_t kRoundTripDefaultCap = 8;
+// shape 0 = the default above; shape 1 = the first shipped shape (<64, 2, 2>: two loads, XCD pairs; wants cap 13),
+// two of its 2-KiB tiles per 4-KiB unit -- kept selectable (tuning key "round_trip_shape") for A/B runs
 template <bool STRICT>
-void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, hipStream_t s) {
-    const uint64_t per_launch = max_tiles_per_launch(64);
+void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(64) / 2;  // in 4-KiB units, valid for both shapes
     const uint32_t lds = lds_for_cap(cap);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
-        hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
-                           in + first * kRoundTripTile, packed + first * (kRoundTripTile / 4), back + first * kRoundTripTile, n_tiles);
+        const uint8_t* i0 = in + first * kRoundTripTile;
+        uint8_t* p0 = packed + first * (kRoundTripTile / 4);
+        uint8_t* b0 = back + first * kRoundTripTile;
+        if (shape == 1)
+            hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(2 * n_tiles)), dim3(64), lds, s, i0, p0, b0, 2 * n_tiles);
+        else
+            hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, n_tiles);
     }
 }
 

@@ -59,7 +59,8 @@ std::atomic<int> g_decode2_variant{0};
 // the generic kernel alone: one launch instead of two or three
 std::atomic<int> g_small_nt{1 << 17};
 std::atomic<int> g_reduce_xi{1};  // hamming / validate tiles take their pages XCD-interleaved (packed_ops_kernels.hpp)
-std::atomic<int> g_round_trip_cap{13};  // resident one-wave workgroups per CU of the fused round-trip kernel
+std::atomic<int> g_round_trip_shape{0};  // 0 = <64, 4, 1> (default), 1 = <64, 2, 2> (the first shipped shape), codec2_launch.hpp
+std::atomic<int> g_round_trip_cap{(int)kRoundTripDefaultCap};  // resident one-wave workgroups per CU of the fused round-trip kernel
 
 inline unsigned generic_grid(uint64_t items) {
     uint64_t b = (items + kBlock - 1) / kBlock;
@@ -401,10 +402,11 @@ int round_trip_dev(const void* d_n, size_t n_len, void* d_bits, size_t out_words
     if (aligned(d_n, 128) && aligned(d_bits, 128) && aligned(d_back, 128)) {
         const uint64_t tiles = n_len / kRoundTripTile;
         const uint32_t cap = (uint32_t)g_round_trip_cap.load(std::memory_order_relaxed);
+        const int shape = g_round_trip_shape.load(std::memory_order_relaxed);
         if (flags & CNT_STRICT_LUT)
-            launch_round_trip<true>(static_cast<const uint8_t*>(d_n), static_cast<uint8_t*>(d_bits), static_cast<uint8_t*>(d_back), tiles, cap, s);
+            launch_round_trip<true>(static_cast<const uint8_t*>(d_n), static_cast<uint8_t*>(d_bits), static_cast<uint8_t*>(d_back), tiles, cap, shape, s);
         else
-            launch_round_trip<false>(static_cast<const uint8_t*>(d_n), static_cast<uint8_t*>(d_bits), static_cast<uint8_t*>(d_back), tiles, cap, s);
+            launch_round_trip<false>(static_cast<const uint8_t*>(d_n), static_cast<uint8_t*>(d_bits), static_cast<uint8_t*>(d_back), tiles, cap, shape, s);
         HIP_TRY(hipGetLastError());
         done = tiles * kRoundTripTile;  // a multiple of 32: the rest starts on a word
     }
@@ -1195,6 +1197,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_cap")) {
         if (value < 0 || value > 32) return CNT_EINVAL;
         g_round_trip_cap.store(value);
+    } else if (!strcmp(key, "round_trip_shape")) {
+        if (value < 0 || value > 1) return CNT_EINVAL;
+        g_round_trip_shape.store(value);
     } else if (!strcmp(key, "reduce_xi")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_xi.store(value);
@@ -1216,6 +1221,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
+    else if (!strcmp(key, "round_trip_shape")) *value = g_round_trip_shape.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;

@@ -210,7 +210,8 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
  * (5-letter codec): value = variant index; cnt_get_tuning also answers "<key>_variants"
  * (the counts).  key "small_nt": inputs of at most this many nucleotides that are not a whole
  * number of tiles take ONE generic-kernel launch instead of tiles + ragged end (default 2^17,
- * 0 = never); "round_trip_cap": resident workgroups per CU of the fused kernel; "reduce_xi":
+ * 0 = never); "round_trip_cap": resident workgroups per CU of the fused kernel, "round_trip_shape": 0 (default: one
+ * wave x four loads, plain order) / 1 (the first shipped shape: two loads, XCD pairs; pair it with cap 13); "reduce_xi":
  * 1 (default) = hamming / validate tiles read their pages XCD-interleaved.
  * cnt_tuning_name returns the variant's description (NULL when out of range).
  * CNT_EINVAL for unknown keys / values. */

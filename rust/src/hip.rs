@@ -9,7 +9,7 @@
 //!
 //! Signatures are identical to the reference's (`n_to_bits.rs:34,51`, `n_to_bits2.rs:37,78`).
 
-use std::os::raw::{c_char, c_int, c_uint};
+use std::os::raw::{c_char, c_int, c_uint, c_void};
 
 #[link(name = "cute_nt_hip")]
 extern "C" {
@@ -24,6 +24,15 @@ extern "C" {
     fn cnt_bits_to_n_sharded(bits: *const u64, words: usize, len: usize, out: *mut u8, ndev: c_int) -> c_int;
     fn cnt_n_to_bits2_sharded(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, ndev: c_int) -> c_int;
     fn cnt_bits_to_n2_sharded(bits: *const u64, words: usize, len: usize, out: *mut u8, ndev: c_int) -> c_int;
+    // device tier (enqueue-only) + the device-memory helpers a caller without HIP bindings needs
+    fn cnt_n_to_bits_dev(d_n: *const c_void, n_len: usize, d_out: *mut c_void, out_words: usize, flags: c_uint, stream: *mut c_void) -> c_int;
+    fn cnt_bits_to_n_dev(d_bits: *const c_void, words: usize, len: usize, d_out: *mut c_void, flags: c_uint, stream: *mut c_void) -> c_int;
+    fn cnt_dev_alloc(d_ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    fn cnt_dev_free(d_ptr: *mut c_void) -> c_int;
+    fn cnt_dev_upload(d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
+    fn cnt_dev_download(h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    fn cnt_dev_sync(stream: *mut c_void) -> c_int;
+    fn cnt_shutdown() -> c_int;
 }
 
 const CNT_STRICT_LUT: c_uint = 1;
@@ -142,6 +151,78 @@ pub fn bits_to_n2_hip_sharded(bits: &[u64], len: usize, ndev: i32) -> Vec<u8> {
     res
 }
 
+// ---- device-resident tier: data already in HBM (what the roofline numbers measure) ------------------
+
+/// Number of packed words for `n_len` nucleotides (`ceil(n_len / 32)`, n_to_bits.rs:35).
+pub fn words_for(n_len: usize) -> usize {
+    unsafe { cnt_words_for(n_len) }
+}
+
+/// Owned device memory on the calling thread's current device (hipMalloc / hipFree behind the C ABI).
+pub struct DeviceBuffer {
+    ptr: *mut c_void,
+    bytes: usize,
+}
+
+impl DeviceBuffer {
+    pub fn new(bytes: usize) -> DeviceBuffer {
+        let mut ptr: *mut c_void = std::ptr::null_mut();
+        unsafe { check(cnt_dev_alloc(&mut ptr, bytes)) };
+        DeviceBuffer { ptr, bytes }
+    }
+
+    pub fn from_slice<T: Copy>(host: &[T]) -> DeviceBuffer {
+        let bytes = std::mem::size_of_val(host);
+        let buf = DeviceBuffer::new(bytes);
+        unsafe { check(cnt_dev_upload(buf.ptr, host.as_ptr() as *const c_void, bytes)) };
+        buf
+    }
+
+    /// Copies the first `len` elements back to the host (synchronous).
+    pub fn to_vec<T: Copy>(&self, len: usize) -> Vec<T> {
+        let bytes = len * std::mem::size_of::<T>();
+        assert!(bytes <= self.bytes);
+        let mut res: Vec<T> = Vec::with_capacity(len);
+        unsafe {
+            check(cnt_dev_download(res.as_mut_ptr() as *mut c_void, self.ptr, bytes));
+            res.set_len(len);
+        }
+        res
+    }
+}
+
+impl Drop for DeviceBuffer {
+    fn drop(&mut self) {
+        unsafe { cnt_dev_free(self.ptr) };
+    }
+}
+
+/// Enqueue the encode of `n_len` device-resident nucleotides into `d_out` (>= `words_for(n_len)` words) on
+/// the default stream; returns without waiting (`device_sync()` waits).
+pub fn n_to_bits_hip_dev(d_n: &DeviceBuffer, n_len: usize, d_out: &DeviceBuffer) {
+    assert!(n_len <= d_n.bytes);
+    unsafe { check(cnt_n_to_bits_dev(d_n.ptr, n_len, d_out.ptr, d_out.bytes / 8, 0, std::ptr::null_mut())) };
+}
+
+/// Enqueue the decode of `len` nucleotides from `words` device-resident words into `d_out` (>= `len` bytes).
+pub fn bits_to_n_hip_dev(d_bits: &DeviceBuffer, words: usize, len: usize, d_out: &DeviceBuffer) {
+    if len > (words << 5) {
+        panic!("The length is greater than the number of nucleotides!");
+    }
+    assert!(words * 8 <= d_bits.bytes && len <= d_out.bytes);
+    unsafe { check(cnt_bits_to_n_dev(d_bits.ptr, words, len, d_out.ptr, 0, std::ptr::null_mut())) };
+}
+
+/// Wait for everything enqueued on the default stream.
+pub fn device_sync() {
+    unsafe { check(cnt_dev_sync(std::ptr::null_mut())) };
+}
+
+/// Release the calling thread's cached streams / staging buffers (and the sharded tier's workers').
+pub fn shutdown() {
+    unsafe { check(cnt_shutdown()) };
+}
+
 #[cfg(test)]
 mod tests {
     use super::*;
@@ -162,6 +243,19 @@ mod tests {
     fn test_n_to_bits2_hip() {
         assert_eq!(n_to_bits2_hip(b"ATCGNATCGNATCGNATCGNATCGNATCGNATCGN"), vec![0x36A45D1F46D48BA3u64, 0x5D1F4]);
         assert_eq!(n_to_bits2_hip(b"ATCGN"), vec![0b101110100011]);
+    }
+
+    #[test]
+    fn test_device_resident_round_trip() {
+        let n = b"ATCGATCGATCGATCGATCGATCGATCGATCG";
+        let d_n = DeviceBuffer::from_slice(&n[..]);
+        let d_bits = DeviceBuffer::new(8);
+        let d_back = DeviceBuffer::new(32);
+        n_to_bits_hip_dev(&d_n, 32, &d_bits);
+        bits_to_n_hip_dev(&d_bits, 1, 32, &d_back);
+        device_sync();
+        assert_eq!(d_bits.to_vec::<u64>(1), vec![0xD8D8D8D8D8D8D8D8u64]);
+        assert_eq!(d_back.to_vec::<u8>(32), n.to_vec());
     }
 
     #[test]

@@ -87,3 +87,68 @@ def test_two_rank_launch_path_shares_one_gpu():
     assert o["encode_read_view_frac"]["min"] <= o["encode_read_view_frac"]["max"]
     sh = j["configs4_sharded_encode"]
     assert sh["ranks_measured"] == 2 and sh["nt_per_gpu"] == 1 << 29 and sh["total_GiB"] == 1.0 and sh["aggregate_gnts"] > 0
+
+
+def test_criterion_twin_runs_and_self_checks():
+    """bench/bench_n_to_bits (the executable C++ twin of the reference's criterion harness,
+    benches/bench_n_to_bits.rs:9-82; the std-only Rust original is rust/benches/bench_n_to_bits.rs) runs on the
+    GPU box: rc 0, one `*_hip` row in each of the reference's four groups + the memcpy comparator, the
+    device-resident rows, and its built-in C-ABI self-checks (every row's output compared with its input or with
+    the reference's 0xD8... vector)."""
+    import re
+
+    exe = os.path.join(ROOT, "bench", "bench_n_to_bits")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    out = subprocess.run([exe, "20"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    rows = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"^(\S+)\s+(.+?)\s+time:\s+([0-9.]+) us\s+thrpt:\s+([0-9.]+) GiB/s", line)
+        if m:
+            rows[(m.group(1), m.group(2).strip())] = (float(m.group(3)), float(m.group(4)))
+    for key in (("n_to_bits", "n_to_bits_hip"), ("n_to_bits", "memcpy"), ("bits_to_n", "bits_to_n_hip"),
+                ("n_to_bits2", "n_to_bits2_hip"), ("bits_to_n2", "bits_to_n2_hip"),
+                ("n_to_bits", "n_to_bits_hip_dev (resident)"), ("bits_to_n", "bits_to_n_hip_dev (resident)"),
+                ("host-tier", "n_to_bits_hip/2^20"), ("host-tier", "cnt_bits_to_n/2^20 (reused out)"),
+                ("device-tier", "n_to_bits_hip_dev/2^20 (resident)"), ("device-tier", "bits_to_n_hip_dev/2^20 (resident)")):
+        assert key in rows, (key, sorted(rows))
+        us, gib = rows[key]
+        assert us > 0 and gib > 0
+    assert rows[("n_to_bits", "n_to_bits_hip")][0] < 200.0  # a 40 000-nt host-slice call is tens of microseconds, not ms
+    assert rows[("device-tier", "n_to_bits_hip_dev/2^20 (resident)")][1] > 20.0  # GiB/s of ASCII, launch-latency-bound at 1 MiB
+    assert "self-check ok" in out.stdout
+    # the Rust original names the same groups and functions (kept in step with the twin by this check)
+    rust = open(os.path.join(ROOT, "rust", "benches", "bench_n_to_bits.rs")).read()
+    for name in ("n_to_bits_lut", "n_to_bits_pext", "n_to_bits_shift", "n_to_bits_movemask", "n_to_bits_mul", "memcpy", "n_to_bits_hip",
+                 "bits_to_n_lut", "bits_to_n_shuffle", "bits_to_n_pdep", "bits_to_n_clmul", "bits_to_n_hip",
+                 "n_to_bits2_lut", "n_to_bits2_pext", "n_to_bits2_hip", "bits_to_n2_lut", "bits_to_n2_pdep", "bits_to_n2_hip"):
+        assert 'bench_function("%s"' % name in rust, name
+    assert "std::time" in rust and "use criterion" not in rust
+
+
+def test_cpu_baseline_and_host_tier_blocks():
+    """the N = 1 line's CPU leg: the port timed on this box's cores (threads, logical and physical cores stated
+    separately), the reference-faithful allocation-inclusive rows incl. the 5-letter functions and the 1 MiB / 1 GiB
+    sizes, and the host-tier crossover table against one CPU thread"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log2-nt", "28",
+                          "--shard-log2-nt", "28", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _last_json(out.stdout)
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Gnt/s" and c["value"] > 1.0
+    d = c["cores_detail"]
+    assert c["cores"] == d["threads_timed"] == d["logical_cpus"] and 1 <= d["physical_cores"] <= d["logical_cpus"] and d["sockets"] >= 1
+    f = c["reference_faithful_40k_GiBs"]
+    for name in ("n_to_bits_lut", "n_to_bits_pext", "n_to_bits_shift", "n_to_bits_movemask", "n_to_bits_mul", "memcpy", "bits_to_n_lut",
+                 "bits_to_n_shuffle", "bits_to_n_pdep", "bits_to_n_clmul", "n_to_bits2_lut", "n_to_bits2_pext", "bits_to_n2_lut", "bits_to_n2_pdep"):
+        assert f[name] > 0, name  # every row of the reference's criterion harness (bench_n_to_bits.rs:15-20,31-32,44-47,59-60)
+    big = c["reference_faithful_GiBs_1thread_alloc_inclusive"]
+    assert len(big["2^20"]) == 10 and len(big["2^30"]) == 10 and big["2^30"]["n_to_bits_movemask"] > 0
+    h = j["host_tier"]
+    assert set(h["rows"]) == {"2^%d" % k for k in (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)}
+    x = h["crossover_vs_one_cpu_thread"]["n_to_bits_hip vs n_to_bits_movemask"]
+    assert x["host_tier_ahead_from"] is None or x["host_tier_ahead_from"] in h["rows"]
+    assert len(x["table_GiBs"]) == 10
