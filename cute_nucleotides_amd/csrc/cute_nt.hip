@@ -59,6 +59,7 @@ std::atomic<int> g_decode2_variant{0};
 // the generic kernel alone: one launch instead of two or three
 std::atomic<int> g_small_nt{1 << 17};
 std::atomic<int> g_reduce_xi{1};  // hamming / validate tiles take their pages XCD-interleaved (packed_ops_kernels.hpp)
+std::atomic<int> g_reduce_fallbacks{0};  // hamming / validate calls that could not get their stream-ordered scratch and ran the generic kernel
 std::atomic<int> g_round_trip_shape{0};  // 0 = <64, 4, 1> (default), 1 = <64, 2, 2> (the first shipped shape), codec2_launch.hpp
 std::atomic<int> g_round_trip_cap{(int)kRoundTripDefaultCap};  // resident one-wave workgroups per CU of the fused round-trip kernel
 
@@ -1222,6 +1223,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
     else if (!strcmp(key, "round_trip_shape")) *value = g_round_trip_shape.load();
+    else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;

@@ -179,7 +179,12 @@ int cnt_dev_sync(void *stream);
  * Layout as above (32 nt per word, A0 C1 T2 G3).  `len` is in nucleotides; inputs hold
  * ceil(len/32) words; bits beyond `len` in the last input word are ignored and written as
  * zero.  Device tier: pointers are device memory, enqueue-only, counters are device u64
- * that the caller zeroes (the call adds to them).  Host tier: synchronous.
+ * that the caller zeroes (the call adds to them).  The two reductions (hamming, validate) take
+ * their per-workgroup partial sums from the STREAM-ORDERED allocator (hipMallocAsync /
+ * hipFreeAsync on the caller's stream, also on the NULL stream): no synchronisation, but unlike
+ * the codec entry points they do allocate; if that allocation fails the call still returns the
+ * right count through a slow one-kernel path, and cnt_get_tuning("reduce_fallbacks") counts
+ * such calls (0 in normal operation).  Host tier: synchronous.
  *   hamming             #{ i < len : code_a(i) != code_b(i) }
  *   complement          A<->T, C<->G
  *   reverse_complement  out(i) = complement(in(len-1-i)); not in place

@@ -263,3 +263,23 @@ def test_sharded_host_tier_throughput_is_sane(L, oracle, alias):
     t_eight = time.perf_counter() - t0
     assert np.array_equal(out, want)
     assert t_eight < 4.0 * t_one + 0.05, (t_one, t_eight)
+
+
+def test_single_process_sharded_bench_script(alias):
+    """bench/bench_sharded_dev.py (configs[4] from one process through cnt_n_to_bits_sharded_dev): four aliased
+    shards of 2^28 nt on the 1-GPU box -- the JSON line, the partition it reports, verified round trip."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNT_SHARD_ALIAS_DEVICES="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench", "bench_sharded_dev.py"), "--ndev", "4", "--log2-nt", "28", "--iters", "3",
+                          "--decode"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["ndev"] == 4 and j["alias_test_hook"] is True and j["verified"] is True and j["data_path_collective"] is None
+    assert j["partition"] == [[k << 28, (k + 1) << 28] for k in range(4)]
+    assert len(j["shard_ms"]) == 4 and all(m > 0 for m in j["shard_ms"]) and j["aggregate_gnts"] > 100 and j["decode_aggregate_gnts"] > 100
+    assert all(d["device_index"] == 0 for d in j["devices"])

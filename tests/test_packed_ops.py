@@ -170,3 +170,5 @@ def test_gpu_large_properties(oracle):
     tail = d[n_len - 1000 :].cpu().numpy()
     head = cn.bits_to_n_dev(rc, 1000).cpu().numpy()
     assert bytes(head) == bytes(tail).translate(COMP)[::-1]
+    # the reductions above took their scratch from the stream-ordered allocator; none fell back to the slow path
+    assert devutil.get_tuning("reduce_fallbacks") == 0
