@@ -19,6 +19,7 @@
 // produced by bench.py's cpu_baseline leg, which is the only bench allowed to call oracle/.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -131,6 +132,20 @@ int main(int argc, char** argv) {
             fprintf(stderr, "C-ABI mismatch at 2^%zu\n", log2);
             return 2;
         }
+        // what the Rust wrappers do: Vec::with_capacity = malloc without zeroing, filled by the library, dropped --
+        // fresh, never-touched pages on every call (the std::vector rows above also pay a single-threaded zero fill)
+        snprintf(nm, sizeof nm, "cnt_n_to_bits/2^%zu (fresh malloc)", log2);
+        bench_function("host-tier", nm, len, [&] {
+            uint64_t* o = static_cast<uint64_t*>(malloc(bits.size() * 8));
+            g_sink += (uint64_t)cnt_n_to_bits(n.data(), len, o, bits.size()) + o[bits.size() - 1];
+            free(o);
+        });
+        snprintf(nm, sizeof nm, "cnt_bits_to_n/2^%zu (fresh malloc)", log2);
+        bench_function("host-tier", nm, len, [&] {
+            uint8_t* o = static_cast<uint8_t*>(malloc(len));
+            g_sink += (uint64_t)cnt_bits_to_n(bits.data(), bits.size(), len, o) + o[len - 1];
+            free(o);
+        });
         if (n_to_bits::bits_to_n_hip(bits, len) != n) {
             fprintf(stderr, "round trip mismatch at 2^%zu\n", log2);
             return 2;

@@ -27,6 +27,7 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
 
 #include "codec2_kernels.hpp"
 #include "codec2_launch.hpp"
@@ -268,6 +269,28 @@ size_t zero_copy_max_nt() {
         return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 20;
     }();
     return v;
+}
+
+// The reference's functions return a FRESH Vec, so the drop-in's copy-out usually lands in pages that have
+// never been touched, and the call is page-fault-bound (1 GiB: 11.5 GiB/s with 4 copy threads against 78 GiB/s
+// into warm pages on the GPU box's host).  Where transparent huge pages are in `madvise` mode (that host, most
+// distributions), advising the 2-MiB-aligned interior of a large output once makes those first touches 2-MiB
+// faults: 45.7 GiB/s with the same 4 threads (bench/fresh_pages_lab.cpp, profiles/r02_fresh_pages_lab.log);
+// through the library, a 1-GiB decode into a fresh malloc -- what Rust's Vec::with_capacity is -- goes from
+// 194 to 72-91 ms, encode from 70 to 35-42 ms (profiles/r02_bench_twin_hugepage_ab.log; 24-25 ms into warm
+// pages).  A team of helper threads that ran ahead of the pipeline taking the faults was tried on top and
+// bought nothing (same log), so it is not here.  Advice only -- a no-op for memory that is already
+// populated, file-backed or under THP=never.  CNT_HOST_HUGEPAGE=0 switches it off.
+void advise_huge_output(void* out, size_t bytes) {
+    static const bool on = [] {
+        const char* e = getenv("CNT_HOST_HUGEPAGE");
+        return !(e && e[0] == '0');
+    }();
+    constexpr uintptr_t kHuge = (uintptr_t)2 << 20;
+    if (!on || bytes < 4 * kHuge) return;
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(out) + kHuge - 1) & ~(kHuge - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(out) + bytes) & ~(kHuge - 1);
+    if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
 }
 
 // ---- device-tier bodies (shared by every tier) ------------------------------------
@@ -544,6 +567,7 @@ int host_encode(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words,
     }
     const size_t chunk = pipeline_chunk(n_len, unit_nt, chunk_nt);
     CNT_TRY(c->ensure(chunk, chunk / unit_nt * 8));
+    advise_huge_output(out, words * 8);
     // 2-slot pipeline: while slot A's H2D / kernel / D2H run on its stream, the host copies slot B's
     // finished output to the caller and stages slot B's next input.
     size_t pend_word[2] = {0, 0}, pend_words[2] = {0, 0};
@@ -601,6 +625,7 @@ int host_decode(const uint64_t* bits, size_t words, size_t len, uint8_t* out, si
     // +32: the reference's SIMD decoders may store whole 32-B blocks; ours never writes past
     // `len`, the slack only keeps device stores inside the scratch.
     CNT_TRY(c->ensure(chunk / unit_nt * 8, chunk + 32));
+    advise_huge_output(out, len);
     size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
     const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(bits);
     auto retire = [&](int slot) -> int {
