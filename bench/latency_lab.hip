@@ -1,5 +1,5 @@
 // latency_lab.hip -- what a SMALL host-tier call costs and how much of it is completion detection.
-// The zero-copy path of the host tier (csrc/cute_nt.hip host_encode: memcpy into pinned staging, ONE
+// The zero-copy path of the host tier (csrc/host_tier.inc host_encode: memcpy into pinned staging, ONE
 // generic-kernel launch that reads / writes pinned memory over PCIe, hipStreamSynchronize, memcpy out)
 // costs 15-19 us at the reference's bench size (40 000 nt); a resident enqueue + sync costs 13 us.  This
 // lab times the same call with different ways of learning that the kernel is done:

@@ -383,7 +383,7 @@ def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda, fullsize):
         assert np.array_equal(got, want), c
 
 
-# ---- any-alignment plan: head peel + funnel-shifted loads (csrc/cute_nt.hip encode_dev/decode_dev) ----
+# ---- any-alignment plan: head peel + funnel-shifted loads (csrc/device_tier.inc encode_dev/decode_dev) ----
 ALIGN_IN_OFFS = [0, 1, 2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 127]
 ALIGN_OUT_WORD_OFFS = [0, 1, 2, 3, 7, 8, 15]
 
