@@ -61,6 +61,18 @@ __global__ __launch_bounds__(kBlock) void encode_flag(const uint8_t* __restrict_
     }
 }
 
+__global__ void empty_kernel() {}
+
+// one thread per output word, the staging buffer is 16-B aligned and zero-padded to a whole word: two 16-B loads
+// issued together (ONE PCIe round trip per thread instead of a chain of byte loads), one 8-B store
+__global__ __launch_bounds__(kBlock) void encode_wide(const uint8_t* __restrict__ n, uint64_t* __restrict__ out, uint64_t n_words) {
+    const uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x;
+    if (w >= n_words) return;
+    const u32x4* p = reinterpret_cast<const u32x4*>(n + 32 * w);
+    const u32x4 a = p[0], b = p[1];
+    out[w] = (uint64_t)enc16<false>(a) | ((uint64_t)enc16<false>(b) << 32);
+}
+
 static inline void spin_until(volatile uint32_t* flag, uint32_t v) {
     while (__atomic_load_n(const_cast<uint32_t*>(flag), __ATOMIC_ACQUIRE) != v) {
 #if defined(__x86_64__)
@@ -93,7 +105,9 @@ int main(int argc, char** argv) {
     auto launch_plain = [&] { hipLaunchKernelGGL((n_to_bits_generic<false>), dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)d_in, (uint64_t)n_len, (uint64_t*)d_out, (uint64_t)0, (uint64_t)words); };
     struct Mode { const char* name; int id; };
     const Mode modes[] = {{"sync   hipStreamSynchronize (shipped)", 0}, {"event  record + hipEventSynchronize", 1}, {"query  spin on hipStreamQuery", 2},
-                          {"wv32   hipStreamWriteValue32 + host spin", 3}, {"sigk   signal kernel + host spin", 4}, {"fused  last-workgroup flag + host spin", 5}};
+                          {"wv32   hipStreamWriteValue32 + host spin", 3}, {"sigk   signal kernel + host spin", 4}, {"fused  last-workgroup flag + host spin", 5},
+                          {"empty  empty kernel + hipStreamSynchronize (floor)", 6}, {"wide   16-B-load kernel + hipStreamSynchronize", 7},
+                          {"wide+sigk  16-B-load kernel + signal kernel + spin", 8}};
     auto one_call = [&](int mode) {
         memcpy(h_in, src.data(), n_len);
         ++tick;
@@ -105,6 +119,10 @@ int main(int argc, char** argv) {
             case 4: launch_plain(); hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)d_flag, tick); spin_until(h_flag, tick); break;
             case 5: hipLaunchKernelGGL(encode_flag, dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)d_in, (uint64_t)n_len, (uint64_t*)d_out, (uint64_t)words, d_counter, (uint32_t*)d_flag, tick);
                     spin_until(h_flag, tick); break;
+            case 6: hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); CK(hipStreamSynchronize(s)); memcpy(h_out, want.data(), words * 8); break;
+            case 7: memset(h_in + n_len, 0, 32); hipLaunchKernelGGL(encode_wide, dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)d_in, (uint64_t*)d_out, (uint64_t)words); CK(hipStreamSynchronize(s)); break;
+            case 8: memset(h_in + n_len, 0, 32); hipLaunchKernelGGL(encode_wide, dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)d_in, (uint64_t*)d_out, (uint64_t)words);
+                    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)d_flag, tick); spin_until(h_flag, tick); break;
         }
         memcpy(dst.data(), h_out, words * 8);
     };

@@ -305,6 +305,20 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
     }
 }
 
+// STAGED: the host tier's small-call path (csrc/host_tier.inc).  The kernel reads the shim's own PINNED
+// staging buffer over PCIe and writes the pinned result buffer: the staging base is 16-B aligned and the
+// host zero-pads the input to a whole word, so a thread takes its 32 nt with two 16-B loads issued
+// together -- ONE PCIe round trip per thread, where the generic kernel's byte loads chain several
+// (bench/latency_lab.hip: 18.8 -> 15.7 us for a 40 000-nt call).  One thread per output word.
+template <bool STRICT>
+__global__ __launch_bounds__(kBlock) void n_to_bits_staged(const uint8_t* __restrict__ n, uint64_t* __restrict__ out, uint64_t n_words) {
+    const uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x;
+    if (w >= n_words) return;
+    const u32x4* p = reinterpret_cast<const u32x4*>(n + 32 * w);
+    const u32x4 a = p[0], b = p[1];
+    out[w] = (uint64_t)enc16<STRICT>(a) | ((uint64_t)enc16<STRICT>(b) << 32);
+}
+
 // ===========================================================================
 // DECODE.  One workgroup = one tile of BLOCK*U*16 nt of OUTPUT.
 // ===========================================================================
@@ -380,6 +394,24 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_lds(const uint8_t* __restrict
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(my[u * kWave + lane])), rout,
                                                ((wave * U + u) * kWave + lane) * 16, 0, SAUX);
+}
+
+// STAGED twin for the host tier's small-call path: one thread per packed word, 8-B load from the pinned staging
+// buffer, all 32 letters written with two 16-B stores into the pinned result buffer (which has room for whole
+// words; the host copies `len` bytes out of it).
+__global__ __launch_bounds__(kBlock) void bits_to_n_staged(const uint64_t* __restrict__ bits, uint8_t* __restrict__ out, uint64_t n_words) {
+    const uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x;
+    if (w >= n_words) return;
+    const uint64_t word = bits[w];
+    u32x4* q = reinterpret_cast<u32x4*>(out + 32 * w);
+    q[0] = dec4((uint32_t)word);
+    q[1] = dec4((uint32_t)(word >> 32));
+}
+
+// completion flag of a small host-tier call: the last kernel of the call on its stream; the host spins on the
+// pinned word instead of going through hipStreamSynchronize (3-4 us of an 18-us call)
+__global__ void raise_flag(uint32_t* flag, uint32_t value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Generic / tail: one thread per packed word, writes min(32, len - 32w) bytes

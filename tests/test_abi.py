@@ -42,7 +42,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "cute_nucleotides_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inc")):
                 src = open(os.path.join(dirpath, f)).read()
                 code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("#", "//", "*", '"""')))
                 assert not re.search(r"^\s*(from|import)\s+oracle", code, re.M), f

@@ -612,3 +612,42 @@ def test_large_ragged_sizes_64bit_indexing(cn, oracle, torch_cuda):
     # strict mode takes the same path with the validity filter
     strict = cn.n_to_bits_dev(d, strict_lut=True)
     assert devutil.count_mismatch(strict, packed) == 0
+
+
+def test_host_tier_small_call_path_staged_kernels(cn, oracle):
+    """Calls up to 2^20 nt take the zero-copy path: the shim's pinned staging buffer, zero-padded to a whole word,
+    read by n_to_bits_staged with 16-B loads (bits_to_n_staged writes whole words into the pinned result buffer),
+    completion through the pinned flag.  Every length 1..200, the reference's bench size, the path's upper limit and
+    one past it (pipeline), both encode semantics on arbitrary bytes, decode of prefixes, and many calls back to
+    back (the flag's tick must never be confused with an earlier call's)."""
+    rng = np.random.default_rng(77)
+    sizes = list(range(1, 201)) + [4095, 4096, 4097, 40000, 65535, (1 << 20) - 1, 1 << 20, (1 << 20) + 1]
+    for n_len in sizes:
+        n = rng.integers(0, 256, n_len, dtype=np.uint8)
+        assert np.array_equal(cn.n_to_bits_hip(n, strict_lut=True), oracle.n_to_bits_lut(n)), n_len
+        v = _rand_valid(n_len, n_len)
+        bits = cn.n_to_bits_hip(v)
+        want = oracle.n_to_bits_lut(v)
+        assert np.array_equal(bits, want), n_len
+        if n_len <= 4097:  # default semantics: (byte>>1)&3 on EVERY byte incl. the ragged tail (include/cute_nt.h)
+            pad = np.zeros(-(-n_len // 32) * 32, dtype=np.uint8)
+            pad[:n_len] = n
+            codes = ((pad >> 1) & 3).astype(np.uint64).reshape(-1, 32)
+            assert np.array_equal(cn.n_to_bits_hip(n), (codes << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)), n_len
+        assert np.array_equal(cn.bits_to_n_hip(bits, n_len), oracle.bits_to_n_lut(want, n_len)), n_len
+        if n_len > 3:
+            assert np.array_equal(cn.bits_to_n_hip(bits, n_len - 3), oracle.bits_to_n_lut(want, n_len - 3)), n_len
+    # arbitrary words decode (bits beyond len ignored), guard bytes behind the caller's buffer untouched
+    words = rng.integers(0, 2**63, 1250, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    import ctypes
+
+    from cute_nucleotides_amd import _lib
+
+    buf = np.full(40000 + 64, 0x2A, dtype=np.uint8)
+    assert _lib.lib().cnt_bits_to_n(ctypes.c_void_p(words.ctypes.data), 1250, 39990, ctypes.c_void_p(buf.ctypes.data)) == 0
+    assert np.array_equal(buf[:39990], oracle.bits_to_n_lut(words, 39990)) and (buf[39990:] == 0x2A).all()
+    a, b = _rand_valid(40000, 1), _rand_valid(40000, 2)
+    wa, wb = oracle.n_to_bits_lut(a), oracle.n_to_bits_lut(b)
+    for k in range(2000):  # alternate inputs so a stale result would be caught
+        got = cn.n_to_bits_hip(a if k & 1 else b)
+        assert np.array_equal(got, wa if k & 1 else wb), k
