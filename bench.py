@@ -27,7 +27,9 @@ ranks (N encoded + N decoded per step and rank), inputs already in HBM.  `roofli
 the n_to_bits encode kernel (the north-star target), `roofline_decode` for bits_to_n; both
 use ALGORITHMIC bytes (1.25 B/nt: encode 1 read + 0.25 written, decode 0.25 read + 1
 written) over the kernel's average duration measured live with HIP events on the
-launch stream.  `cpu_baseline` times the oracle's ports of the reference's fastest AVX2
+launch stream; `roofline.traffic` = HBM bytes per launch measured by this run itself (two child `rocprofv3 --pmc`
+passes, FETCH_SIZE and WRITE_SIZE separately, calibrated on known-size probes; falls back to the committed
+profiles/hbm_traffic.json, and says so in `traffic_source`).  `cpu_baseline` times the oracle's ports of the reference's fastest AVX2
 paths (n_to_bits_movemask / bits_to_n_shuffle) on this box's host cores, rank 0, N=1 only.
 """
 import argparse
@@ -58,6 +60,7 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline time budget (0 = skip)")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="headline only: skip the ceilings, the configs block and the fused pass")
+    p.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs; quote profiles/hbm_traffic.json")
     p.add_argument("--shard-log2-nt", type=int, default=35, help="per-GPU shard of BASELINE.json configs[4] (256 GiB over 8 GPUs = 2^35 nt each)")
     return p.parse_args()
 
@@ -355,6 +358,42 @@ def crossover(host_rows, cpu_rows):
     return out
 
 
+def measure_traffic_live(log2_nt, timeout_s=240):
+    """HBM bytes per launch of the two timed kernels, measured by THIS run on THIS box: two child processes of
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has 4 counter slots,
+    3 + 2 do not fit; counters are never combined with any other tracing domain) over bench/pmc_workload.py
+    --codec-only, i.e. a read-only and a write-only probe of known size for the calibration (gfx950 reports half of
+    wide coalesced reads, MI355X_MICROARCH.md section HBM) followed by the encode and decode kernels at the same
+    size as the headline.  Returns the summary of bench/parse_profiles.py:traffic_summary, or {"error": ...}."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    sys.path.insert(0, os.path.join(ROOT, "bench"))
+    import parse_profiles
+
+    tmp = tempfile.mkdtemp(prefix="cnt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        csvs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench", "pmc_workload.py"), "--log2-nt", str(log2_nt), "--reps", "2", "--codec-only"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            csvs[counter] = os.path.join(out, "pmc_counter_collection.csv")
+            if r.returncode != 0 or not os.path.exists(csvs[counter]):
+                return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout[-300:])}
+        return parse_profiles.traffic_summary(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], 1 << log2_nt, "live")
+    except Exception as exc:  # noqa: BLE001 -- the headline must not die with its evidence leg
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -621,9 +660,16 @@ def main():
         value = nt_per_step * args.steps / elapsed / 1e9
         enc_gbs = gbs(BYTES_PER_NT * n_len, enc_ms)
         dec_gbs = gbs(BYTES_PER_NT * n_len, dec_ms)
-        traffic, traffic_source = None, None
+        traffic, traffic_source, live = None, None, None
+        if world == 1 and extras and not args.no_live_traffic and not os.environ.get("ROCPROFILER_SDK_TOOL_LIBRARIES") and not os.environ.get("ROCP_TOOL_LIBRARIES"):
+            live = measure_traffic_live(args.log2_nt)  # all of this process's device buffers are free by now
+            if "error" not in live:
+                traffic = {"encode_bytes_per_launch": live["encode"]["hbm_bytes"], "decode_bytes_per_launch": live["decode"]["hbm_bytes"]}
+                traffic_source = ("measured by this run on this box: child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes "
+                                  "over bench/pmc_workload.py --codec-only (2 launches each), calibrated on read-only / write-only probes of "
+                                  "known size in the same pass (fetch x%.3f, write x%.3f)" % (live["calibration"]["fetch_scale"], live["calibration"]["write_scale"]))
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and args.log2_nt == 34:
+        if traffic is None and os.path.exists(tpath) and args.log2_nt == 34:
             try:
                 traffic = json.load(open(tpath))
                 traffic_source = ("static: profiles/hbm_traffic.json, from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
@@ -669,6 +715,7 @@ def main():
                 "frac_at_min": round(gbs(BYTES_PER_NT * n_len, dec_st["min"]) / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": int(BYTES_PER_NT * n_len),
             },
+            "traffic_live": live,
             "roofline_over_ranks": {"encode_frac": span("encode_frac"), "decode_frac": span("decode_frac"),
                                     "encode_read_view_frac": span("encode_read_view_frac")},
             "ranks": rows,

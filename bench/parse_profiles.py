@@ -35,21 +35,10 @@ def pick(d, needle):
     return hits[0]
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    log2_nt = int(sys.argv[2]) if len(sys.argv) > 2 else 34
-    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    dst = os.path.join(ROOT, "profiles")
-    os.makedirs(dst, exist_ok=True)
-    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
-    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
-    f36 = os.path.join(src, "stats_fused36", "fused36_kernel_stats.csv")
-    if os.path.exists(f36):  # rocprofv3 --stats of a 2^36-nt fused round trip (BASELINE.json configs[3])
-        shutil.copy(f36, os.path.join(dst, tag + "_fused_2p36_kernel_stats.csv"))
-        shutil.copy(os.path.join(src, "fused36_under_rocprof.jsonl"), os.path.join(dst, tag + "_fused_2p36_under_rocprof.jsonl"))
-    fetch = means(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"))
-    write = means(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"))
-    n = 1 << log2_nt
+def traffic_summary(fetch_csv, write_csv, n, tag=""):
+    """Calibrated HBM bytes per launch from one FETCH_SIZE pass and one WRITE_SIZE pass over bench/pmc_workload.py
+    (n = nucleotides of the workload): the read-only / write-only probes of known size give the scale factors."""
+    fetch, write = means(fetch_csv), means(write_csv)
     k_read, k_write = pick(fetch, "k_read<"), pick(write, "k_write<")
     f_cal = n / (fetch[k_read][0] * 1024.0)   # true bytes per reported FETCH_SIZE byte
     w_cal = n / (write[k_write][0] * 1024.0)
@@ -79,8 +68,27 @@ def main():
         hits = [k for k in fetch if needle in k]
         if len(hits) == 1:
             summary[key] = traffic(hits[0], alg)
+    return summary
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    log2_nt = int(sys.argv[2]) if len(sys.argv) > 2 else 34
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
+    f36 = os.path.join(src, "stats_fused36", "fused36_kernel_stats.csv")
+    if os.path.exists(f36):  # rocprofv3 --stats of a 2^36-nt fused round trip (BASELINE.json configs[3])
+        shutil.copy(f36, os.path.join(dst, tag + "_fused_2p36_kernel_stats.csv"))
+        shutil.copy(os.path.join(src, "fused36_under_rocprof.jsonl"), os.path.join(dst, tag + "_fused_2p36_under_rocprof.jsonl"))
+    n = 1 << log2_nt
+    summary = traffic_summary(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"),
+                              os.path.join(src, "pmc_write", "pmc_counter_collection.csv"), n, tag)
     json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
-    json.dump({"source": "profiles/%s_pmc_summary.json" % tag, "nt": n, "kernels": [enc.split("(")[0], dec.split("(")[0]],
+    json.dump({"source": "profiles/%s_pmc_summary.json" % tag, "nt": n,
+               "kernels": [summary["encode"]["kernel"].split("(")[0], summary["decode"]["kernel"].split("(")[0]],
                "encode_bytes_per_launch": summary["encode"]["hbm_bytes"],
                "decode_bytes_per_launch": summary["decode"]["hbm_bytes"]},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)

@@ -19,6 +19,7 @@ from cute_nucleotides_amd import devutil  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--codec-only", action="store_true", help="calibration probes + the two 2-bit codec kernels only (bench.py's live traffic leg)")
 a = ap.parse_args()
 n = 1 << a.log2_nt
 d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -37,6 +38,9 @@ for _ in range(a.reps):
     cn.bits_to_n_dev(d_packed, n, out=d_out)
 torch.cuda.synchronize()
 assert devutil.count_mismatch(d_in, d_out) == 0
+if a.codec_only:
+    print("pmc workload ok (codec only): n = 2^%d, reps = %d" % (a.log2_nt, a.reps))
+    raise SystemExit(0)
 # secondary kernels: 5-letter codec on a 27*2^28-nt prefix of the same buffers, packed-domain ops
 from cute_nucleotides_amd import packed_ops as po  # noqa: E402
 

@@ -22,7 +22,7 @@ def _last_json(text):
 
 def test_single_gpu_line_small():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log2-nt", "30",
-                          "--shard-log2-nt", "31", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "--shard-log2-nt", "31", "--cpu-seconds", "0", "--no-live-traffic"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _last_json(out.stdout)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["verified"] is True
@@ -152,3 +152,11 @@ def test_cpu_baseline_and_host_tier_blocks():
     x = h["crossover_vs_one_cpu_thread"]["n_to_bits_hip vs n_to_bits_movemask"]
     assert x["host_tier_ahead_from"] is None or x["host_tier_ahead_from"] in h["rows"]
     assert len(x["table_GiBs"]) == 10
+    # roofline.traffic: HBM bytes per launch measured by THIS run (two rocprofv3 --pmc child passes, calibrated on
+    # known-size probes) -- equal to the algorithmic bytes to well under 1 %: nothing is re-read
+    for key in ("roofline", "roofline_decode"):
+        r = j[key]
+        assert r["traffic_source"].startswith("measured by this run"), j.get("traffic_live")
+        assert abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1.0) < 0.01, (key, r["traffic"], r["algorithmic_bytes_per_launch"])
+    cal = j["traffic_live"]["calibration"]
+    assert 1.5 < cal["fetch_scale"] < 2.5 and 0.8 < cal["write_scale"] < 1.25
