@@ -53,8 +53,8 @@ BYTES_PER_NT = 1.25    # algorithmic bytes per nucleotide, each direction (SURVE
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--log2-nt", type=int, default=34, help="per-GPU nucleotides = 2^k (default 34 = 16 GiB, the metric size)")
     p.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     p.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline time budget (0 = skip)")
@@ -785,12 +785,16 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             if extras:
-                line["host_tier"] = {
-                    "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread, "
-                            "GiB/s of nucleotides; `fresh out` allocates the output inside the timed call like the reference's functions do",
-                    "rows": measure_host_tier(args.seed)}
+                rows = measure_host_tier(args.seed)
                 cpu_rows = line["cpu_baseline"].get("reference_faithful_GiBs_1thread_alloc_inclusive") or {}
-                line["host_tier"]["crossover_vs_one_cpu_thread"] = crossover(line["host_tier"]["rows"], cpu_rows)
+                names = ("n_to_bits_hip reused out", "bits_to_n_hip reused out", "n_to_bits_hip fresh out", "bits_to_n_hip fresh out")
+                line["host_tier"] = {
+                    "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread; "
+                            "`fresh out` allocates the output inside the timed call like the reference's functions do; microseconds per call "
+                            "at 2^k nt (GiB/s of the fresh-out calls are in the crossover table)",
+                    "log2_nt": list(HOST_TIER_LOG2),
+                    "us_per_call": {nm: [rows["2^%d" % k][nm + " us"] for k in HOST_TIER_LOG2] for nm in names},
+                    "crossover_vs_one_cpu_thread": crossover(rows, cpu_rows)}
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Print DESIGN.md's "round N in one table" from a bench.py JSON line, so the table is the file's numbers and
+nothing else:   python bench/design_table.py profiles/r02_bench_final.json"""
+import json
+import sys
+
+j = json.load(open(sys.argv[1]))
+c = j["ceilings"]["rank0"]
+tb = lambda gbs: "%.2f" % (gbs / 1000.0)
+fr = lambda gbs: "%.3f" % (gbs / 8000.0)
+r, d, f = j["roofline"], j["roofline_decode"], j["fused_round_trip"]
+cfg = j["configs"]
+k1 = cfg["configs[1] n_to_bits encode, 1 GiB (2^30 nt)"]
+k2 = cfg["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]
+k3 = cfg.get("configs[3] encode + decode as two passes, 64 GiB (2^36 nt)", {})
+k3f = cfg.get("configs[3] fused round trip, 64 GiB (2^36 nt)", {})
+s4 = j["configs4_sharded_encode"]
+ev, dv = j["ceilings"]["encode_vs"], j["ceilings"]["decode_vs"]
+rows = [
+    ("read-only probe / write-only probe / 1 : 1 copy", "%s / %s / %s" % (tb(c["read_only"]["GBs"]), tb(c["write_only"]["GBs"]), tb(c["copy_1to1"]["GBs"])),
+     "%s / %s / %s" % (fr(c["read_only"]["GBs"]), fr(c["write_only"]["GBs"]), fr(c["copy_1to1"]["GBs"])), "—"),
+    ("4 : 1 probe (encode's shape) / 1 : 4 probe (decode's shape)", "%s / %s" % (tb(c["read4_write1_encode_shape"]["GBs"]), tb(c["read1_write4_decode_shape"]["GBs"])),
+     "%s / %s" % (fr(c["read4_write1_encode_shape"]["GBs"]), fr(c["read1_write4_decode_shape"]["GBs"])), "—"),
+    ("`n_to_bits` (mean of %d timed launches %.3f ms; median %.3f, min %.3f)" % (r["kernel_ms"]["n"], r["kernel_ms"]["mean"], r["kernel_ms"]["median"], r["kernel_ms"]["min"]),
+     tb(r["achieved"]), "**%.3f**" % r["frac"], "%.3f" % ev["of_read4_write1_ceiling"]),
+    ("— read-only view (the north star's \"fraction of HBM *read* bandwidth\")", tb(r["read_only_view"]["achieved"]), "**%.3f**" % r["read_only_view"]["frac"],
+     "%.3f of the read-only probe" % ev["read_only_view_of_read_only_ceiling"]),
+    ("`bits_to_n` (mean %.3f ms; median %.3f, min %.3f)" % (d["kernel_ms"]["mean"], d["kernel_ms"]["median"], d["kernel_ms"]["min"]), tb(d["achieved"]), "**%.3f**" % d["frac"],
+     "%.3f" % dv["of_read1_write4_ceiling"]),
+    ("fused round trip, 2^34 / 2^36 nt", "%s / %s" % (tb(f["achieved"]), tb(k3f.get("achieved_GBs", 0))), "%.3f / %.3f" % (f["frac"], k3f.get("frac", 0)), "—"),
+    ("`configs[1]` / `[2]`: 1 GiB encode / decode", "%s / %s" % (tb(k1["achieved_GBs"]), tb(k2["achieved_GBs"])), "%.3f / %.3f" % (k1["frac"], k2["frac"]),
+     "(0.2 ms launches; the 256 MiB of words sit in the Infinity Cache)"),
+    ("`configs[3]`: 64 GiB, two passes", tb(k3.get("achieved_GBs", 0)), "%.3f" % k3.get("frac", 0), "—"),
+    ("`configs[4]`: one GPU's 2^35-nt shard, encode", tb(1.25 * s4["per_gpu_gnts"]["min"]), "%.3f (read view %.3f)" % (s4["per_gpu_frac"]["min"], s4["per_gpu_read_view_frac"]["min"]), "—"),
+]
+print("| 2^34 nt, one MI355X | TB/s | of 8 TB/s | of its own no-arithmetic ceiling |")
+print("|---|---|---|---|")
+for row in rows:
+    print("| " + " | ".join(row) + " |")
+print()
+print("value = %.2f Tnt/s; traffic %s / %s bytes per launch (%s)" % (j["value"] / 1000.0, r["traffic"], d["traffic"], (r.get("traffic_source") or "")[:40]))
+cb = j.get("cpu_baseline")
+if cb:
+    print("cpu: all-core %.0f Gnt/s (enc %.0f, dec %.0f), one thread %.0f; cores %s" % (cb["value"], cb["encode_gnts"], cb["decode_gnts"], cb["one_thread"]["value"], cb["cores_detail"]))
+    x = j["host_tier"]["crossover_vs_one_cpu_thread"]
+    for k, v in x.items():
+        print("crossover", k, v["host_tier_ahead_from"])

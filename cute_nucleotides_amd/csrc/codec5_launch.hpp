@@ -29,6 +29,14 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 13
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 10 wg/CU", 2 * kWaveBytes5, 64, 10},  // 14
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 24 wg/CU", 2 * kWaveBytes5, 64, 24},  // 15: the default before the caps were re-swept
+    // round 2: 4 words per lane (6912 B of ASCII per wave) was only ever measured uncapped (variant 1); the fused 2-bit
+    // kernel's sweep says fat one-wave tiles want a LOW residency cap
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 7 wg/CU", 4 * kWaveBytes5, 64, 7},    // 16
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 8 wg/CU", 4 * kWaveBytes5, 64, 8},    // 17
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 9 wg/CU", 4 * kWaveBytes5, 64, 9},    // 18
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 10 wg/CU", 4 * kWaveBytes5, 64, 10},  // 19
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 12 wg/CU", 4 * kWaveBytes5, 64, 12},  // 20
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc0|sc1|nt, 8 wg/CU", 4 * kWaveBytes5, 64, 8},  // 21
 };
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
@@ -55,6 +63,13 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 19: the default before the XCD group size was re-swept
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc0|sc1|nt, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 20
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc0|sc1|nt, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 21
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 7 wg/CU", 4 * kWaveBytes5, 64, 7},    // 22
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 8 wg/CU", 4 * kWaveBytes5, 64, 8},    // 23
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 9 wg/CU", 4 * kWaveBytes5, 64, 9},    // 24
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 10 wg/CU", 4 * kWaveBytes5, 64, 10},  // 25
+    {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 12 wg/CU", 4 * kWaveBytes5, 64, 12},  // 26
+    {"wave-tiled 4 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 8 wg/CU", 4 * kWaveBytes5, 64, 8},  // 27
+    {"wave-tiled 4 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 9 wg/CU", 4 * kWaveBytes5, 64, 9},  // 28
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -70,7 +85,9 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile_nt;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_words * 8;
-        const uint32_t lds = kEncode2Variants[variant].wg_cap ? lds_for_cap(kEncode2Variants[variant].wg_cap) - 3584u : 0u;  // slab is 3488 B static
+        // the static slab is 3488 B (2 words per lane) / 6944 B (4 words per lane), allocated in 512-B granules
+        const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;
+        const uint32_t lds = kEncode2Variants[variant].wg_cap ? lds_for_cap(kEncode2Variants[variant].wg_cap) - slab : 0u;
 #define CNT_ENC2(W, P, L, S) \
     hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
@@ -81,6 +98,8 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
             case 4: CNT_ENC2(1, 1, kNT, kSC1); break;
             case 5: CNT_ENC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: case 11: case 12: case 13: case 14: case 15: CNT_ENC2(1, 2, kNT, kSC1); break;
+            case 16: case 17: case 18: case 19: case 20: CNT_ENC2(1, 4, kNT, kSC1); break;
+            case 21: CNT_ENC2(1, 4, kNT, kSC0 | kSC1 | kNT); break;
             case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             default: return 1;
@@ -116,7 +135,8 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * tile_words * 8;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_nt;
-        const uint32_t lds = kDecode2Variants[variant].wg_cap ? lds_for_cap(kDecode2Variants[variant].wg_cap) - 3584u : 0u;  // slab is 3488 B static
+        const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;  // static slab, see launch_encode2
+        const uint32_t lds = kDecode2Variants[variant].wg_cap ? lds_for_cap(kDecode2Variants[variant].wg_cap) - slab : 0u;
 #define CNT_DEC2(W, P, L, S) \
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
         switch (variant) {
@@ -129,6 +149,8 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 5: CNT_DEC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
             case 9: case 13: case 14: case 15: CNT_DEC2(1, 2, 0, kAll); break;
+            case 22: case 23: case 24: case 25: case 26: CNT_DEC2(1, 4, 0, kAll); break;
+            case 27: case 28: hipLaunchKernelGGL((bits_to_n2_wave<1, 4, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
             default: return 1;
         }

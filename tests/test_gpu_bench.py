@@ -148,9 +148,10 @@ def test_cpu_baseline_and_host_tier_blocks():
     big = c["reference_faithful_GiBs_1thread_alloc_inclusive"]
     assert len(big["2^20"]) == 10 and len(big["2^30"]) == 10 and big["2^30"]["n_to_bits_movemask"] > 0
     h = j["host_tier"]
-    assert set(h["rows"]) == {"2^%d" % k for k in (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)}
+    assert h["log2_nt"] == [12, 14, 16, 18, 20, 22, 24, 26, 28, 30]
+    assert all(len(v) == 10 and min(v) > 1.0 for v in h["us_per_call"].values()) and len(h["us_per_call"]) == 4
     x = h["crossover_vs_one_cpu_thread"]["n_to_bits_hip vs n_to_bits_movemask"]
-    assert x["host_tier_ahead_from"] is None or x["host_tier_ahead_from"] in h["rows"]
+    assert x["host_tier_ahead_from"] is None or x["host_tier_ahead_from"] in x["table_GiBs"]
     assert len(x["table_GiBs"]) == 10
     # roofline.traffic: HBM bytes per launch measured by THIS run (two rocprofv3 --pmc child passes, calibrated on
     # known-size probes) -- equal to the algorithmic bytes to well under 1 %: nothing is re-read
