@@ -91,6 +91,61 @@ inline std::vector<uint8_t> bits_to_n2_hip(const std::vector<uint64_t>& bits, si
     return bits_to_n2_hip(bits.data(), bits.size(), len);
 }
 
+/// The 5-letter codec over `ndev` GPUs (shards are whole 128-word tiles), no collective.
+inline std::vector<uint64_t> n_to_bits2_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
+    std::vector<uint64_t> out(cnt_words2_for(len));
+    detail::check(cnt_n_to_bits2_sharded(n, len, out.data(), out.size(), ndev));
+    return out;
+}
+inline std::vector<uint8_t> bits_to_n2_hip_sharded(const uint64_t* bits, size_t words, size_t len, int ndev = 0) {
+    if (words > SIZE_MAX / 27 || len > words * 27) detail::check(CNT_ELEN);
+    std::vector<uint8_t> out(len);
+    detail::check(cnt_bits_to_n2_sharded(bits, words, len, out.data(), ndev));
+    return out;
+}
+
 }  // namespace n_to_bits2
+
+/// Device-resident tier for C++ callers that do not link HIP themselves (the same shape as the Rust binding's
+/// `DeviceBuffer` / `n_to_bits_hip_dev`, rust/src/hip.rs): data already in HBM, enqueue on the default stream,
+/// `sync()` waits.  This is the tier the roofline numbers measure.
+namespace device {
+
+class DeviceBuffer {
+   public:
+    explicit DeviceBuffer(size_t bytes) : bytes_(bytes) { detail::check(cnt_dev_alloc(&ptr_, bytes)); }
+    DeviceBuffer(const void* host, size_t bytes) : DeviceBuffer(bytes) { detail::check(cnt_dev_upload(ptr_, host, bytes)); }
+    ~DeviceBuffer() { (void)cnt_dev_free(ptr_); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    void* data() const { return ptr_; }
+    size_t size_bytes() const { return bytes_; }
+    template <typename T>
+    std::vector<T> to_vector(size_t count) const {  // synchronous copy back to the host
+        if (count * sizeof(T) > bytes_) throw std::out_of_range("DeviceBuffer::to_vector");
+        std::vector<T> out(count);
+        detail::check(cnt_dev_download(out.data(), ptr_, count * sizeof(T)));
+        return out;
+    }
+
+   private:
+    void* ptr_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+/// Enqueue the encode of `n_len` resident nucleotides into `out` (>= cnt_words_for(n_len) words).
+inline void n_to_bits_hip_dev(const DeviceBuffer& n, size_t n_len, DeviceBuffer& out, bool strict_lut = false) {
+    if (n_len > n.size_bytes()) throw std::out_of_range("n_to_bits_hip_dev: n_len");
+    detail::check(cnt_n_to_bits_dev(n.data(), n_len, out.data(), out.size_bytes() / 8, strict_lut ? CNT_STRICT_LUT : 0u, nullptr));
+}
+/// Enqueue the decode of `len` nucleotides from `words` resident words into `out` (>= len bytes).
+inline void bits_to_n_hip_dev(const DeviceBuffer& bits, size_t words, size_t len, DeviceBuffer& out) {
+    if (len > (words << 5)) detail::check(CNT_ELEN);
+    if (words * 8 > bits.size_bytes() || len > out.size_bytes()) throw std::out_of_range("bits_to_n_hip_dev: sizes");
+    detail::check(cnt_bits_to_n_dev(bits.data(), words, len, out.data(), 0u, nullptr));
+}
+inline void sync() { detail::check(cnt_dev_sync(nullptr)); }
+
+}  // namespace device
 
 }  // namespace cute_nucleotides

@@ -1,0 +1,56 @@
+"""bench.py's host-side helpers, checked without a GPU: the numpy restatement it uses to spot-check the TIMED
+packed buffer is the oracle's function, the crossover rule, the per-kernel statistics, and the table generator
+reproduces DESIGN.md's round-2 table from the committed bench line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_numpy_pack_is_the_oracle_on_whole_words(oracle):
+    import bench
+
+    rng = np.random.default_rng(3)
+    for n_len in (32, 64, 32 * 1000):
+        n = rng.integers(0, 256, n_len, dtype=np.uint8)
+        assert np.array_equal(bench.numpy_pack(n), oracle.n_to_bits_bitextract(n))  # (byte>>1)&3 on whole words
+        v = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)[rng.integers(0, 10, n_len)]
+        assert np.array_equal(bench.numpy_pack(v), oracle.n_to_bits_lut(v))  # == n_to_bits_lut on the alphabet
+    assert bench.numpy_pack(np.frombuffer(b"ATCG" * 8, dtype=np.uint8)).tolist() == [0xD8D8D8D8D8D8D8D8]  # n_to_bits.rs:414-415
+
+
+def test_stats_and_crossover():
+    import bench
+
+    s = bench.stats_ms([3.0, 1.0, 2.0, 10.0])
+    assert s == {"mean": 4.0, "median": 2.5, "min": 1.0, "max": 10.0, "n": 4}
+    host = {"2^12": {"n_to_bits_hip fresh out": 1.0, "bits_to_n_hip fresh out": 1.0},
+            "2^20": {"n_to_bits_hip fresh out": 50.0, "bits_to_n_hip fresh out": 5.0},
+            "2^30": {"n_to_bits_hip fresh out": 30.0, "bits_to_n_hip fresh out": 14.0}}
+    cpu = {"2^12": {"n_to_bits_movemask": 60.0, "bits_to_n_shuffle": 30.0}, "2^20": {"n_to_bits_movemask": 40.0, "bits_to_n_shuffle": 70.0},
+           "2^30": {"n_to_bits_movemask": 35.0, "bits_to_n_shuffle": 4.0}}
+    x = bench.crossover(host, cpu)
+    # ahead at 2^20 but behind again at 2^30: "ahead from" means ahead at every larger size too
+    assert x["n_to_bits_hip vs n_to_bits_movemask"]["host_tier_ahead_from"] is None
+    assert x["bits_to_n_hip vs bits_to_n_shuffle"]["host_tier_ahead_from"] == "2^30"
+    assert bench.physical_cores(sorted(os.sched_getaffinity(0))) in (None,) + tuple(range(1, 4097))
+    assert bench.gbs(8e12, 1000.0) == 8000.0
+
+
+def test_design_table_is_generated_from_the_committed_line():
+    line = os.path.join(ROOT, "profiles", "r02_bench_final.json")
+    j = json.load(open(line))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "design_table.py"), line], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    table = out.stdout.split("\n\n")[0]
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert table in design, "DESIGN.md's round-2 table is not the committed bench line's numbers: re-run bench/design_table.py"
+    # the line itself is internally consistent
+    r = j["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic_source"].startswith("measured by this run")
+    assert abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1) < 1e-3
+    assert j["verified"] is True and j["n_gpus"] == 1 and j["ranks"][0]["pci_bus_id"]
