@@ -1,10 +1,16 @@
 """Randomised differential test of the HIP path against the oracle: random lengths (biased to
 tile edges), random 16-B/8-B/1-B pointer offsets, both codecs, both encode modes, device tier.
 Deterministic seeds; a few hundred cases in a few seconds."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# CNT_FUZZ_SEEDS=N multiplies the number of seeds of every test in this file (soak runs: `CNT_FUZZ_SEEDS=50
+# python -m pytest tests/test_gpu_fuzz.py -m gpu -q`, a few minutes; profiles/r02_fuzz_soak.log is one such run)
+SEEDS = max(1, int(os.environ.get("CNT_FUZZ_SEEDS", "1")))
 
 EDGES = [0, 1, 2, 3, 26, 27, 31, 32, 33, 63, 64, 2047, 2048, 2049, 3455, 3456, 3457, 4095, 4096, 4097,
          32767, 32768, 32769, 65535, 65536]
@@ -29,7 +35,7 @@ def small_nt(request):
     devutil.set_tuning("small_nt", saved)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 * SEEDS))
 def test_two_bit_codec_fuzz(oracle, small_nt, seed):
     import torch
 
@@ -67,7 +73,7 @@ def test_two_bit_codec_fuzz(oracle, small_nt, seed):
         assert (d[:off_d] == 0x5A).all() and (d[off_d + length :] == 0x5A).all()
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 * SEEDS))
 def test_five_letter_codec_fuzz(oracle, small_nt, seed):
     import torch
 
@@ -91,3 +97,73 @@ def test_five_letter_codec_fuzz(oracle, small_nt, seed):
         d = dout.cpu().numpy()
         assert np.array_equal(d[off_d : off_d + length], oracle.bits_to_n2_lut(want, length)), (seed, n_len, length)
         assert (d[:off_d] == 0x5A).all() and (d[off_d + length :] == 0x5A).all()
+
+
+@pytest.mark.parametrize("seed", range(3 * SEEDS))
+def test_host_and_sharded_tiers_fuzz(oracle, seed, monkeypatch):
+    """host-slice entry points: the zero-copy small path (staged kernels + completion flag), the 2-slot pipeline, and
+    the sharded tier with a random number of aliased shards -- random lengths around every path's limits, both codecs,
+    arbitrary bytes for the 2-bit encoder in both modes"""
+    import ctypes
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import _lib, n_to_bits2 as n2
+
+    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")
+    L = _lib.lib()
+    rng = np.random.default_rng(500 + seed)
+    alpha = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
+    alpha5 = np.frombuffer(b"ACGTNacgtnUu", dtype=np.uint8)
+    limits = [1, 27, 32, 4096, 13824, 16384, 40000, 1 << 20, (1 << 20) + 1, 1 << 22, 3 << 20]
+    for _ in range(10):
+        n_len = max(1, int(rng.choice(limits)) + int(rng.integers(-40, 41)))
+        strict = bool(rng.integers(0, 2))
+        n = rng.integers(0, 256, n_len, dtype=np.uint8) if strict else alpha[rng.integers(0, 10, n_len)]
+        want = oracle.n_to_bits_lut(n)
+        assert np.array_equal(cn.n_to_bits_hip(n, strict_lut=strict), want), (seed, n_len, strict)
+        length = int(rng.integers(0, n_len + 1))
+        assert np.array_equal(cn.bits_to_n_hip(want, length), oracle.bits_to_n_lut(want, length)), (seed, n_len, length)
+        ndev = int(rng.integers(1, 10))
+        v = alpha[rng.integers(0, 10, n_len)]
+        wv = oracle.n_to_bits_lut(v)
+        assert np.array_equal(cn.n_to_bits_hip_sharded(v, ndev=ndev), wv), (seed, n_len, ndev)
+        assert np.array_equal(cn.bits_to_n_hip_sharded(wv, length, ndev=ndev), oracle.bits_to_n_lut(wv, length)), (seed, n_len, ndev, length)
+        n5 = alpha5[rng.integers(0, 12, n_len)]
+        w5 = oracle.n_to_bits2_lut(n5)
+        assert np.array_equal(n2.n_to_bits2_hip(n5), w5), (seed, n_len)
+        assert np.array_equal(n2.n_to_bits2_hip_sharded(n5, ndev=ndev), w5), (seed, n_len, ndev)
+        assert np.array_equal(n2.bits_to_n2_hip_sharded(w5, length, ndev=ndev), oracle.bits_to_n2_lut(w5, length)), (seed, n_len, ndev, length)
+        # capacity / length errors still come first
+        assert L.cnt_n_to_bits_sharded(ctypes.c_void_p(v.ctypes.data), n_len, ctypes.c_void_p(wv.ctypes.data), max(wv.size - 1, 0), ndev) == _lib.CNT_ECAP
+
+
+@pytest.mark.parametrize("seed", range(2 * SEEDS))
+def test_fused_and_packed_ops_fuzz(oracle, seed):
+    """fused round trip == encode then decode (oracle), and the packed-domain ops against their oracle definitions,
+    on random lengths and pointer phases"""
+    import torch
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import packed_ops as po
+
+    rng = np.random.default_rng(900 + seed)
+    alpha = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
+    for n_len in _lengths(rng, 12):
+        if n_len == 0:
+            continue
+        strict = bool(rng.integers(0, 2))
+        n = rng.integers(0, 256, n_len, dtype=np.uint8) if strict else alpha[rng.integers(0, 10, n_len)]
+        off = int(rng.choice([0, 0, 128, 1, 16]))
+        buf = torch.zeros(n_len + 256, dtype=torch.uint8, device="cuda")
+        view = buf[off : off + n_len]
+        view.copy_(torch.from_numpy(n))
+        bits, back = cn.round_trip_dev(view, strict_lut=strict)
+        want = oracle.n_to_bits_lut(n)
+        assert np.array_equal(bits.cpu().numpy().view(np.uint64), want), (seed, n_len, off, strict)
+        assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(want, n_len)), (seed, n_len, off, strict)
+        other = oracle.n_to_bits_lut(alpha[rng.integers(0, 10, n_len)])
+        d_other = torch.from_numpy(other.view(np.int64)).cuda()
+        assert int(po.hamming_dev(bits, d_other, n_len).item()) == oracle.hamming(want, other, n_len), (seed, n_len)
+        assert np.array_equal(po.complement_dev(bits, n_len).cpu().numpy().view(np.uint64), oracle.complement(want, n_len)), (seed, n_len)
+        assert np.array_equal(po.reverse_complement_dev(bits, n_len).cpu().numpy().view(np.uint64), oracle.reverse_complement(want, n_len)), (seed, n_len)
+        assert int(po.validate_dev(view).item()) == oracle.validate(n), (seed, n_len)
