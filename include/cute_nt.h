@@ -128,7 +128,9 @@ int cnt_shard_worker_info(int k, int *device, int *numa_node, int *n_cpus, int *
 /* Arrays of ndev entries; shard k is device memory ON DEVICE k (ndev <= 0: all visible
  * devices; with the test hook above: device k % count).  The calling thread enqueues every
  * shard on a library-owned stream of its device -- the devices then run concurrently -- and
- * returns when all have finished: no host staging, no collective, no helper threads.  Per-shard
+ * returns when all have finished: no host staging, no collective, no helper threads.  The streams
+ * are the library's own (non-blocking), so whatever produced the shards must be COMPLETE before the
+ * call (synchronise the producing streams first); the outputs are complete when it returns.  Per-shard
  * contracts are those of cnt_n_to_bits_dev / cnt_bits_to_n_dev (any alignment, ragged sizes,
  * empty shards allowed).  shard_ms (optional, ndev floats): each shard's device time between
  * HIP events on its stream.  The calling thread's current device is restored. */
