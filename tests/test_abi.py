@@ -180,3 +180,38 @@ def test_worker_info_needs_a_sharded_call_first(L):
     from cute_nucleotides_amd import _lib
 
     assert L.cnt_shard_worker_info(0, None, None, None, None) == _lib.CNT_EINVAL
+
+
+def test_every_tier_fails_loudly_without_a_device(L):
+    """There is no CPU fallback: on a box without a HIP device every compute entry point returns an error status
+    (CNT_ENODEV from the host / sharded tiers, -(hipErrorNoDevice) from the device tier) -- it never computes on the
+    host and never crashes.  Argument errors and empty inputs are still answered."""
+    from cute_nucleotides_amd import _lib
+
+    count = ctypes.c_int(-1)
+    assert L.cnt_device_count(ctypes.byref(count)) == 0
+    if count.value != 0:
+        pytest.skip("a HIP device is visible here; this test is about the box without one")
+    n = np.frombuffer(b"ACGT" * 16, dtype=np.uint8)
+    out = np.full(2, 0x5555555555555555, dtype=np.uint64)
+    buf = np.full(64, 0x2A, dtype=np.uint8)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for rc in (L.cnt_n_to_bits(p(n), 64, p(out), 2), L.cnt_bits_to_n(p(out), 2, 64, p(buf)), L.cnt_n_to_bits2(p(n), 64, p(out), 3),
+               L.cnt_bits_to_n2(p(out), 2, 54, p(buf)), L.cnt_n_to_bits_sharded(p(n), 64, p(out), 2, 2), L.cnt_bits_to_n2_sharded(p(out), 2, 54, p(buf), 0)):
+        assert rc == _lib.CNT_ENODEV, rc
+    assert L.cnt_n_to_bits_dev(p(n), 64, p(out), 2, 0, None) < 0 and L.cnt_round_trip_dev(p(n), 64, p(out), 2, p(buf), 0, None) != 0
+    ptrs, sizes = (ctypes.c_void_p * 1)(n.ctypes.data), (ctypes.c_size_t * 1)(64)
+    outs, caps = (ctypes.c_void_p * 1)(out.ctypes.data), (ctypes.c_size_t * 1)(2)
+    assert L.cnt_n_to_bits_sharded_dev(ptrs, sizes, outs, caps, 1, 0, None) == _lib.CNT_ENODEV
+    d = ctypes.c_void_p()
+    assert L.cnt_dev_alloc(ctypes.byref(d), 64) < 0 and not d.value
+    assert L.cnt_device_pci_bus_id(0, ctypes.create_string_buffer(64), 64) == _lib.CNT_ENODEV
+    assert (out == 0x5555555555555555).all() and (buf == 0x2A).all()  # nothing was computed anywhere
+    # still answered without a device: empty inputs, argument errors, the partition, shutdown
+    assert L.cnt_n_to_bits(None, 0, None, 0) == 0 and L.cnt_bits_to_n_sharded(None, 0, 0, None, 4) == 0
+    assert L.cnt_n_to_bits(p(n), 64, p(out), 1) == _lib.CNT_ECAP and L.cnt_bits_to_n(p(out), 1, 33, p(buf)) == _lib.CNT_ELEN
+    assert L.cnt_shutdown() == 0
+    with pytest.raises(_lib.CuteNtError):
+        import cute_nucleotides_amd as cn
+
+        cn.n_to_bits_hip(b"ACGT")
