@@ -37,6 +37,7 @@ import ctypes
 import glob
 import json
 import os
+import shutil
 import statistics
 import sys
 import time
@@ -224,6 +225,8 @@ def cpu_baseline(seconds):
         "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3),
                        "note": "one thread over the whole sample"},
         "scalar_lut_encode_gnts_1thread": round(lut_enc, 3), "cpu_model": model,
+        "reference_toolchain": {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc"),
+                                "note": "kind is 'port' because the reference (Rust) cannot be built where no cargo/rustc exists"},
     }
 
 
@@ -558,6 +561,19 @@ def main():
                             "frac": round(gbs(BYTES_PER_NT * m, st["median"]) / HBM_PEAK_GBS, 4)}
         if verified is not None:
             configs["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]["round_trip_verified"] = devutil.count_mismatch(d_in[:m], d_out[:m]) == 0
+        # a size that is not a multiple of 32 (tail kernels, zero-padded last word) in the same run
+        r = m - 19  # 2^30 - 19 = 32 * (2^25 - 1) + 13: thirteen nucleotides in the last word
+        if n_len >= r:
+            er = timed_calls(torch, lambda: cn.n_to_bits_dev(d_in[:r], out=d_packed[: r // 32 + 1]), 10, warm=2)
+            dr = timed_calls(torch, lambda: cn.bits_to_n_dev(d_packed[: r // 32 + 1], r, out=d_out[:r]), 10, warm=2)
+            assert r % 32 == 13
+            row = {"encode_ms": stats_ms(er), "decode_ms": stats_ms(dr),
+                   "encode_frac": round(gbs(BYTES_PER_NT * r, statistics.median(er)) / HBM_PEAK_GBS, 4),
+                   "decode_frac": round(gbs(BYTES_PER_NT * r, statistics.median(dr)) / HBM_PEAK_GBS, 4)}
+            if verified is not None:
+                last = int(d_packed[r // 32].item()) & 0xFFFFFFFFFFFFFFFF
+                row["round_trip_verified"] = devutil.count_mismatch(d_in[:r], d_out[:r]) == 0 and (last >> 26) == 0  # 13 nt used, 38 high bits zero
+            configs["ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)"] = row
 
     # ---- same-run, same-box ceilings: no-arithmetic streams issued like the shipped kernels -------
     ceilings = None
