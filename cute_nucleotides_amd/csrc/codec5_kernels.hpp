@@ -277,12 +277,12 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         v[i] = u32x4{0, 0, 0, 0};
-        if ((i + 1) * 64 <= TILE_VECS || lane < TILE_VECS - i * 64)
+        if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64))
             v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-        if ((i + 1) * 64 <= TILE_VECS || lane < TILE_VECS - i * 64) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
+        if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64)) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
     wave_lds_fence();
     typedef unsigned int vu2 __attribute__((__vector_size__(8)));
 #pragma unroll
@@ -314,12 +314,12 @@ __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restric
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         v[i] = u32x4{0, 0, 0, 0};
-        if ((i + 1) * 64 <= WIN_VECS || lane < WIN_VECS - i * 64)
+        if ((i + 1) * 64 <= WIN_VECS || lane < (uint32_t)(WIN_VECS - i * 64))
             v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-        if ((i + 1) * 64 <= WIN_VECS || lane < WIN_VECS - i * 64) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
+        if ((i + 1) * 64 <= WIN_VECS || lane < (uint32_t)(WIN_VECS - i * 64)) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
     wave_lds_fence();
     typedef unsigned int vu2 __attribute__((__vector_size__(8)));
 #pragma unroll
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
     constexpr int NST = (TILE_VECS + 63) / 64;
 #pragma unroll
     for (int i = 0; i < NST; ++i)
-        if ((i + 1) * 64 <= TILE_VECS || lane < TILE_VECS - i * 64) {
+        if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64)) {
             const u32x4 o = *reinterpret_cast<const u32x4*>(my + (i * 64 + lane) * 4);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
         }
