@@ -84,6 +84,37 @@ __global__ __launch_bounds__(64) void pwrite_run(uint8_t* __restrict__ out, uint
     }
 }
 
+// Step 2: the ENCODE as persistent waves with a deep software pipeline -- lab 4's persistent kernels prefetched ONE
+// tile (1-2 KiB per wave) and topped out at 5.7 TB/s; the probes above say a persistent wave needs >= 8 KiB in flight.
+// Wave g of G takes the contiguous RUN-KiB pieces g, g+G, ...: while it packs and stores piece t (RUN dword stores
+// of 256 B each = RUN/4 KiB of consecutive output) the RUN loads of piece t+G are already in flight.
+template <int RUN, int SAUX>
+__global__ __launch_bounds__(64) void enc_persist_deep(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_runs) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t G = gridDim.x, g = blockIdx.x;
+    if (g >= n_runs) return;
+    u32x4 cur[RUN], nxt[RUN];
+    {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(in + g * (RUN * 1024ull), RUN * 1024);
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) cur[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (d * 64 + lane) * 16, 0, kNT));
+    }
+    for (uint64_t t = g; t < n_runs; t += G) {
+        const bool more = t + G < n_runs;
+        if (more) {
+            const __amdgpu_buffer_rsrc_t r = rsrc_of(in + (t + G) * (RUN * 1024ull), RUN * 1024);
+#pragma unroll
+            for (int d = 0; d < RUN; ++d) nxt[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (d * 64 + lane) * 16, 0, kNT));
+        }
+        const __amdgpu_buffer_rsrc_t ro = rsrc_of(out + t * (RUN * 256ull), RUN * 256);
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) __builtin_amdgcn_raw_buffer_store_b32(enc16<false>(cur[d]), ro, (d * 64 + lane) * 4, 0, SAUX);
+        if (!more) break;
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) cur[d] = nxt[d];
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(64) void pwrite(uint8_t* __restrict__ out, uint64_t n_tiles) {
     const uint32_t lane = threadIdx.x;
@@ -109,6 +140,9 @@ template <int RUN> void add_rr(int wpc) { char n[96]; snprintf(n, 96, "persisten
 template <int RUN> void add_wr(int wpc) { char n[96]; snprintf(n, 96, "persistent write run=%-2d KiB waves/CU=%-2d", RUN, wpc); const uint64_t t = N / (RUN * 1024ull); const unsigned g = 256u * wpc;
     vs.push_back({n, [t, g](hipStream_t s) { hipLaunchKernelGGL((pwrite_run<RUN>), dim3(g), dim3(64), 0, s, d_b, t); }, {}, (double)N}); }
 
+template <int RUN, int SAUX> void add_enc(int wpc) { char n[96]; snprintf(n, 96, "persistent ENCODE run=%-2d KiB st=%-2d waves/CU=%-2d", RUN, SAUX, wpc); const uint64_t t = N / (RUN * 1024ull); const unsigned g = 256u * wpc;
+    vs.push_back({n, [t, g](hipStream_t s) { hipLaunchKernelGGL((enc_persist_deep<RUN, SAUX>), dim3(g), dim3(64), 0, s, d_a, d_b, t); }, {}, 1.25 * (double)N}); }
+
 template <int BLOCK, int U>
 __global__ __launch_bounds__(BLOCK) void oneshot_read(const uint8_t* __restrict__ in, uint8_t* __restrict__ sink, uint64_t n_tiles) {
     constexpr uint32_t TILE = BLOCK * U * 16;
@@ -131,6 +165,10 @@ int main(int argc, char** argv) {
         for (int w : {4, 8, 12, 16, 24, 32}) { add_r<4>(w); add_r<8>(w); add_r<16>(w); }
         add_r<32>(4); add_r<32>(8);
         for (int w : {4, 8, 16, 32}) add_w(w);
+    } else if (set == 2) {
+        { const uint64_t t = N / 2048; vs.push_back({"one-shot ENCODE shipped (64 thr x 2, pairs, cap 23)", [t](hipStream_t st) { hipLaunchKernelGGL((n_to_bits_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, false>), dim3((unsigned)t), dim3(64), 6912, st, d_a, d_b, t); }, {}, 1.25 * (double)N}); }
+        for (int w : {2, 3, 4, 5, 6, 8, 12}) { add_enc<4, 19>(w); add_enc<8, 19>(w); add_enc<16, 19>(w); }
+        for (int w : {2, 4}) { add_enc<32, 19>(w); add_enc<16, 16>(w); add_enc<8, 16>(w); }
     } else {
         for (int w : {2, 4, 6, 8, 12}) { add_rr<4>(w); add_rr<8>(w); add_rr<16>(w); add_rr<32>(w); }
         for (int w : {1, 2, 4, 6, 8, 12, 16}) { add_wr<2>(w); add_wr<4>(w); add_wr<8>(w); add_wr<16>(w); }
