@@ -651,3 +651,30 @@ def test_host_tier_small_call_path_staged_kernels(cn, oracle):
     for k in range(2000):  # alternate inputs so a stale result would be caught
         got = cn.n_to_bits_hip(a if k & 1 else b)
         assert np.array_equal(got, wa if k & 1 else wb), k
+
+
+def test_small_call_path_is_thread_safe(cn, oracle):
+    """eight threads hammer the zero-copy small-call path (own pinned staging, own completion word per thread and
+    device) with different inputs of different sizes; every result must be its own"""
+    import threading
+
+    bad = []
+
+    def work(k):
+        rng = np.random.default_rng(k)
+        inputs = [_rand_valid(int(s), 1000 * k + i) for i, s in enumerate(rng.integers(1, 70000, 6))]
+        wants = [oracle.n_to_bits_lut(x) for x in inputs]
+        for it in range(400):
+            j = it % len(inputs)
+            bits = cn.n_to_bits_hip(inputs[j])
+            if not np.array_equal(bits, wants[j]):
+                bad.append((k, it, "enc"))
+                return
+            if it % 7 == 0 and not np.array_equal(cn.bits_to_n_hip(bits, inputs[j].size), oracle.bits_to_n_lut(wants[j], inputs[j].size)):
+                bad.append((k, it, "dec"))
+                return
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad, bad[:5]
