@@ -17,9 +17,11 @@ from cute_nucleotides_amd import devutil, packed_ops as po  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--reduce-persistent", type=int, default=1, help="1 = one launch of persistent waves (shipped); 0 = round 1's tiles + scratch + second pass")
 ap.add_argument("--reduce-xi", type=int, default=1, help="XCD-interleaved pages for the reductions (tuning key reduce_xi)")
 a = ap.parse_args()
 devutil.set_tuning("reduce_xi", a.reduce_xi)
+devutil.set_tuning("reduce_persistent", a.reduce_persistent)
 n = 1 << a.log2_nt
 d = torch.empty(n, dtype=torch.uint8, device="cuda")
 devutil.fill_random_acgt(d, 1)
@@ -29,25 +31,29 @@ y = cn.n_to_bits_dev(d)
 out = torch.empty_like(x)
 
 
-def timed(fn):
+def timed(fn, inner=5):
+    """median over a.iters measurements of `inner` back-to-back calls between two events (per call): the Python
+    wrapper needs 20-50 us before each launch, which a single-call measurement would count as GPU time"""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
     ts = []
     for _ in range(a.iters):
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
         e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / inner)
     ts.sort()
     return ts[len(ts) // 2]
 
 
+acc = torch.zeros(1, dtype=torch.int64, device="cuda")  # the reductions ADD to a caller-owned counter: no kernel but theirs in the timing
 rows = [
-    ("hamming", 0.5, lambda: po.hamming_dev(x, y, n)),
+    ("hamming", 0.5, lambda: po.hamming_dev(x, y, n, acc=acc)),
     ("complement", 0.5, lambda: po.complement_dev(x, n, out=out)),
     ("reverse_complement", 0.5, lambda: po.reverse_complement_dev(x, n, out=out)),
-    ("validate", 1.0, lambda: po.validate_dev(d)),
+    ("validate", 1.0, lambda: po.validate_dev(d, acc=acc)),
 ]
 dist = int(po.hamming_dev(x, y, n).item())
 assert abs(dist / n - 0.75) < 0.001, dist  # two independent uniform sequences differ in 3/4 of the positions

@@ -69,6 +69,7 @@ std::atomic<int> g_decode2_variant{0};
 // the generic kernel alone: one launch instead of two or three
 std::atomic<int> g_small_nt{1 << 17};
 std::atomic<int> g_reduce_xi{1};  // hamming / validate tiles take their pages XCD-interleaved (packed_ops_kernels.hpp)
+std::atomic<int> g_reduce_persistent{1};  // 1 = hamming / validate as one launch of persistent waves (default); 0 = tiles + scratch + second pass (round 1)
 std::atomic<int> g_reduce_fallbacks{0};  // hamming / validate calls that could not get their stream-ordered scratch and ran the generic kernel
 std::atomic<int> g_round_trip_shape{0};  // 0 = <64, 4, 1> (default), 1 = <64, 2, 2> (the first shipped shape), codec2_launch.hpp
 std::atomic<int> g_round_trip_cap{(int)kRoundTripDefaultCap};  // resident one-wave workgroups per CU of the fused round-trip kernel
@@ -339,6 +340,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_shape")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_round_trip_shape.store(value);
+    } else if (!strcmp(key, "reduce_persistent")) {
+        if (value < 0 || value > 1) return CNT_EINVAL;
+        g_reduce_persistent.store(value);
     } else if (!strcmp(key, "reduce_xi")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_xi.store(value);
@@ -362,6 +366,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
     else if (!strcmp(key, "round_trip_shape")) *value = g_round_trip_shape.load();
     else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
+    else if (!strcmp(key, "reduce_persistent")) *value = g_reduce_persistent.load();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;

@@ -123,6 +123,58 @@ __global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __rest
     block_sum_store(c, partial);
 }
 
+// ---- persistent reductions (the shipped form since round 2) ------------------------------------------------
+// A reduction has no stores, so a wave can stay resident, walk its share of the buffer with a deep software
+// pipeline and finish with ONE atomic: wave g of G takes the contiguous RUN-KiB pieces g, g+G, g+2G, ... (chip-wide
+// the waves read one compact, advancing window), the RUN (x2 streams) 1-KiB loads of the next piece are in flight
+// while the current piece is counted.  bench/tune_lab14/15.hip: a few such waves per CU read at 7.2-7.4 TB/s, as
+// fast as the one-shot tiles -- and a call is one launch with ~10^3 atomics instead of tiles + a stream-ordered
+// scratch array (hipMallocAsync) + a second kernel + a free, which cost the API call 60-100 us on top of a 1.2 ms
+// kernel (hamming 0.82-0.86 -> 0.90-0.92 of the roofline at the entry point).  No allocation: capturable in a graph.
+__device__ __forceinline__ void wave_sum_to(uint64_t v, unsigned long long* dst) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0 && v) (void)__hip_atomic_fetch_add(dst, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int kHammingRunKiB = 8, kHammingWavesPerCU = 2;     // bench/tune_lab15.hip
+constexpr int kValidateRunKiB = 16, kValidateWavesPerCU = 4;
+constexpr unsigned kCUs = 256;                                 // MI355X
+
+template <int RUN>
+__global__ __launch_bounds__(64) void hamming_persist(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t n_runs,
+                                                      unsigned long long* __restrict__ count) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t G = gridDim.x, g = blockIdx.x;
+    if (g >= n_runs) return;
+    u32x4 va[RUN], vb[RUN];
+    {
+        const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + g * (RUN * 1024ull), RUN * 1024), rb = rsrc_of(b + g * (RUN * 1024ull), RUN * 1024);
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) {
+            va[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (d * 64 + lane) * 16, 0, kNT));
+            vb[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (d * 64 + lane) * 16, 0, kNT));
+        }
+    }
+    uint64_t total = 0;
+    for (uint64_t t = g; t < n_runs; t += G) {
+        const uint64_t nx = t + G < n_runs ? t + G : t;  // the last iteration re-reads its own piece; it is counted once
+        const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + nx * (RUN * 1024ull), RUN * 1024), rb = rsrc_of(b + nx * (RUN * 1024ull), RUN * 1024);
+        uint32_t c = 0;
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) {
+            c += diff_codes32(va[d].x, vb[d].x) + diff_codes32(va[d].y, vb[d].y) + diff_codes32(va[d].z, vb[d].z) + diff_codes32(va[d].w, vb[d].w);
+            va[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (d * 64 + lane) * 16, 0, kNT));
+            vb[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (d * 64 + lane) * 16, 0, kNT));
+        }
+        total += c;
+    }
+    wave_sum_to(total, count);
+}
+
 // generic / tail: one thread per word from first_word, last word masked to `len`
 __global__ __launch_bounds__(kRedBlock) void hamming_generic(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
                                                              uint64_t len, uint64_t first_word, uint64_t n_words,
@@ -253,6 +305,32 @@ __global__ __launch_bounds__(kRedBlock) void validate_tiles(const uint8_t* __res
     for (int u = 0; u < U; ++u)
         c += invalid_bytes32<ALLOW_N>(v[u].x) + invalid_bytes32<ALLOW_N>(v[u].y) + invalid_bytes32<ALLOW_N>(v[u].z) + invalid_bytes32<ALLOW_N>(v[u].w);
     block_sum_store(c, partial);
+}
+
+template <int RUN, bool ALLOW_N>
+__global__ __launch_bounds__(64) void validate_persist(const uint8_t* __restrict__ n, uint64_t n_runs, unsigned long long* __restrict__ count) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t G = gridDim.x, g = blockIdx.x;
+    if (g >= n_runs) return;
+    u32x4 v[RUN];
+    {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(n + g * (RUN * 1024ull), RUN * 1024);
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) v[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (d * 64 + lane) * 16, 0, kNT));
+    }
+    uint64_t total = 0;
+    for (uint64_t t = g; t < n_runs; t += G) {
+        const uint64_t nx = t + G < n_runs ? t + G : t;
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(n + nx * (RUN * 1024ull), RUN * 1024);
+        uint32_t c = 0;
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) {
+            c += invalid_bytes32<ALLOW_N>(v[d].x) + invalid_bytes32<ALLOW_N>(v[d].y) + invalid_bytes32<ALLOW_N>(v[d].z) + invalid_bytes32<ALLOW_N>(v[d].w);
+            v[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (d * 64 + lane) * 16, 0, kNT));
+        }
+        total += c;
+    }
+    wave_sum_to(total, count);
 }
 
 template <bool ALLOW_N>

@@ -53,7 +53,17 @@ def validate_hip(n, allow_n=False):
 
 
 # ---- device tier --------------------------------------------------------------------------
-def hamming_dev(a, b, length):
+def _counter(torch, acc, like):
+    """the device u64 a reduction adds into: a fresh zeroed scalar, or the caller's (which the CALLER zeroes --
+    the C entry points add to it, so several calls can accumulate into one counter without a kernel in between)"""
+    if acc is None:
+        return torch.zeros(1, dtype=torch.int64, device=like.device)
+    if acc.dtype != torch.int64 or not acc.is_cuda or acc.device != like.device or acc.numel() < 1 or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous int64 CUDA tensor on the input's device")
+    return acc
+
+
+def hamming_dev(a, b, length, acc=None):
     torch = _dev_guard(a)
     _dev_guard(b)
     if a.dtype != torch.int64 or b.dtype != torch.int64:
@@ -62,7 +72,7 @@ def hamming_dev(a, b, length):
         raise ValueError("both sequences must live on the same device")
     if length > min(a.numel(), b.numel()) * 32:
         raise ValueError("The length is greater than the number of nucleotides!")
-    acc = torch.zeros(1, dtype=torch.int64, device=a.device)
+    acc = _counter(torch, acc, a)
     _enqueue(a, lib().cnt_hamming_dev, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), length, ctypes.c_void_p(acc.data_ptr()))
     return acc  # device scalar: .item() syncs
 
@@ -87,10 +97,10 @@ def reverse_complement_dev(bits, length, out=None):
     return _unary_dev(lib().cnt_reverse_complement_dev, bits, length, out)
 
 
-def validate_dev(n, allow_n=False):
+def validate_dev(n, allow_n=False, acc=None):
     torch = _dev_guard(n)
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
-    acc = torch.zeros(1, dtype=torch.int64, device=n.device)
+    acc = _counter(torch, acc, n)
     _enqueue(n, lib().cnt_validate_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), CNT_ALLOW_N if allow_n else 0, ctypes.c_void_p(acc.data_ptr()))
     return acc

@@ -181,12 +181,13 @@ int cnt_dev_sync(void *stream);
  * Layout as above (32 nt per word, A0 C1 T2 G3).  `len` is in nucleotides; inputs hold
  * ceil(len/32) words; bits beyond `len` in the last input word are ignored and written as
  * zero.  Device tier: pointers are device memory, enqueue-only, counters are device u64
- * that the caller zeroes (the call adds to them).  The two reductions (hamming, validate) take
- * their per-workgroup partial sums from the STREAM-ORDERED allocator (hipMallocAsync /
- * hipFreeAsync on the caller's stream, also on the NULL stream): no synchronisation, but unlike
- * the codec entry points they do allocate; if that allocation fails the call still returns the
- * right count through a slow one-kernel path, and cnt_get_tuning("reduce_fallbacks") counts
- * such calls (0 in normal operation).  Host tier: synchronous.
+ * that the caller zeroes (the call adds to them).  Like the codec entry points these neither
+ * synchronise nor allocate (capturable in a HIP graph): the two reductions (hamming, validate)
+ * are ONE launch of persistent waves that end in one atomic each.  (Round 1's form -- tiles, a
+ * stream-ordered scratch array from hipMallocAsync, a second kernel -- stays selectable with
+ * cnt_set_tuning("reduce_persistent", 0) for A/B runs; only that form allocates, and
+ * cnt_get_tuning("reduce_fallbacks") counts the calls in which its allocation failed.)
+ * Host tier: synchronous.
  *   hamming             #{ i < len : code_a(i) != code_b(i) }
  *   complement          A<->T, C<->G
  *   reverse_complement  out(i) = complement(in(len-1-i)); not in place
@@ -218,8 +219,9 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
  * (the counts).  key "small_nt": inputs of at most this many nucleotides that are not a whole
  * number of tiles take ONE generic-kernel launch instead of tiles + ragged end (default 2^17,
  * 0 = never); "round_trip_cap": resident workgroups per CU of the fused kernel, "round_trip_shape": 0 (default: one
- * wave x four loads, plain order) / 1 (the first shipped shape: two loads, XCD pairs; pair it with cap 13); "reduce_xi":
- * 1 (default) = hamming / validate tiles read their pages XCD-interleaved.
+ * wave x four loads, plain order) / 1 (the first shipped shape: two loads, XCD pairs; pair it with cap 13); "reduce_persistent":
+ * 1 (default) = hamming / validate as one launch of persistent waves, 0 = round 1's tiles + scratch + second pass, whose
+ * tiles read their pages XCD-interleaved when "reduce_xi" is 1.
  * cnt_tuning_name returns the variant's description (NULL when out of range).
  * CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);
