@@ -172,3 +172,56 @@ def test_gpu_large_properties(oracle):
     assert bytes(head) == bytes(tail).translate(COMP)[::-1]
     # the reductions above took their scratch from the stream-ordered allocator; none fell back to the slow path
     assert devutil.get_tuning("reduce_fallbacks") == 0
+
+
+@gpu
+def test_reductions_are_graph_capturable_and_accumulate(oracle):
+    """Since round 2 hamming / validate neither synchronise nor allocate (one launch of persistent waves): a whole
+    encode -> hamming -> validate chain records into a HIP graph and replays on new buffer contents; the counters are
+    the caller's and the calls ADD to them (two calls into one counter = the sum)."""
+    import torch
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import packed_ops as po
+
+    n_len = (1 << 21) + 4099  # tiles' worth of persistent pieces plus a ragged tail and a word tail
+    rng = np.random.default_rng(9)
+    d_a = torch.zeros(n_len, dtype=torch.uint8, device="cuda")
+    d_b = torch.zeros(n_len, dtype=torch.uint8, device="cuda")
+    p_a = torch.zeros((n_len + 31) // 32, dtype=torch.int64, device="cuda")
+    p_b = torch.zeros_like(p_a)
+    ham = torch.zeros(1, dtype=torch.int64, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def chain():
+        ham.zero_()
+        bad.zero_()
+        cn.n_to_bits_dev(d_a, out=p_a)
+        cn.n_to_bits_dev(d_b, out=p_b)
+        po.hamming_dev(p_a, p_b, n_len, acc=ham)
+        po.validate_dev(d_a, acc=bad)
+        po.validate_dev(d_b, acc=bad)  # accumulates into the same counter
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        chain()  # warm-up outside capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chain()
+    for seed in (1, 2, 3):
+        a = _ascii(rng, n_len)
+        b = _ascii(rng, n_len)
+        b[rng.integers(0, n_len, 50)] = ord("N")
+        a[7] = 0
+        d_a.copy_(torch.from_numpy(a))
+        d_b.copy_(torch.from_numpy(b))
+        g.replay()
+        torch.cuda.synchronize()
+        # expected values from the oracle's definitions on what the encoder makes of the bytes
+        pa, pb = p_a.cpu().numpy().view(np.uint64), p_b.cpu().numpy().view(np.uint64)
+        assert int(ham.item()) == oracle.hamming(pa, pb, n_len), seed
+        assert int(bad.item()) == oracle.validate(a) + oracle.validate(b), seed
+        assert oracle.validate(a) >= 1 and oracle.validate(b) >= 1
+    with pytest.raises(ValueError):
+        po.hamming_dev(p_a, p_b, n_len, acc=torch.zeros(1, dtype=torch.int32, device="cuda"))
