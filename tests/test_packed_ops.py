@@ -51,9 +51,20 @@ gpu = pytest.mark.gpu
 SIZES = [0, 1, 5, 31, 32, 33, 63, 64, 65, 1000, 4099, 32 * 8192, 32 * 8192 + 7, (1 << 22) + 13, 3 * (1 << 21) + 64]
 
 
+@pytest.fixture(params=[1, 0], ids=["persistent", "tiles+second-pass"])
+def reduce_form(request):
+    """both forms of the reductions: one launch of persistent waves (shipped) and round 1's tiles + stream-ordered
+    scratch + second pass (selectable for A/B runs: tuning key reduce_persistent)"""
+    from cute_nucleotides_amd import devutil
+
+    devutil.set_tuning("reduce_persistent", request.param)
+    yield request.param
+    devutil.set_tuning("reduce_persistent", 1)
+
+
 @gpu
 @pytest.mark.parametrize("n_len", SIZES)
-def test_gpu_ops_match_oracle(oracle, n_len):
+def test_gpu_ops_match_oracle(oracle, n_len, reduce_form):
     import torch
 
     from cute_nucleotides_amd import packed_ops as po
@@ -80,7 +91,7 @@ def test_gpu_ops_match_oracle(oracle, n_len):
 
 
 @gpu
-def test_gpu_validate(oracle):
+def test_gpu_validate(oracle, reduce_form):
     import torch
 
     from cute_nucleotides_amd import packed_ops as po
@@ -100,7 +111,7 @@ def test_gpu_validate(oracle):
 
 
 @gpu
-def test_gpu_ops_pointer_phases(oracle):
+def test_gpu_ops_pointer_phases(oracle, reduce_form):
     """Word pointers at every 8-B phase of a 128-B line (equal and unequal phases of the two
     streams), ASCII pointers at odd bytes: heads are peeled, results and guard words unchanged."""
     import torch
