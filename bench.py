@@ -361,7 +361,7 @@ def crossover(host_rows, cpu_rows):
     return out
 
 
-def measure_traffic_live(log2_nt, timeout_s=240):
+def measure_traffic_live(log2_nt, timeout_s=90):
     """HBM bytes per launch of the two timed kernels, measured by THIS run on THIS box: two child processes of
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has 4 counter slots,
     3 + 2 do not fit; counters are never combined with any other tracing domain) over bench/pmc_workload.py
