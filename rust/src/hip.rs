@@ -33,6 +33,11 @@ extern "C" {
     fn cnt_dev_download(h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     fn cnt_dev_sync(stream: *mut c_void) -> c_int;
     fn cnt_shutdown() -> c_int;
+    // packed-domain operations (host tier): what the reference's README points to, on the packed words
+    fn cnt_hamming(a: *const u64, b: *const u64, len: usize, distance: *mut u64) -> c_int;
+    fn cnt_complement(bits: *const u64, len: usize, out: *mut u64) -> c_int;
+    fn cnt_reverse_complement(bits: *const u64, len: usize, out: *mut u64) -> c_int;
+    fn cnt_validate(n: *const u8, n_len: usize, flags: c_uint, invalid: *mut u64) -> c_int;
 }
 
 const CNT_STRICT_LUT: c_uint = 1;
@@ -151,6 +156,54 @@ pub fn bits_to_n2_hip_sharded(bits: &[u64], len: usize, ndev: i32) -> Vec<u8> {
     res
 }
 
+// ---- operations on the packed words without decoding (README.md:20-25,45 of the reference) ----------------
+
+fn need(bits: &[u64], len: usize) {
+    if len > (bits.len() << 5) {
+        panic!("The length is greater than the number of nucleotides!");
+    }
+}
+
+/// Number of positions `i < len` whose 2-bit codes differ.
+pub fn hamming_hip(a: &[u64], b: &[u64], len: usize) -> u64 {
+    need(a, len);
+    need(b, len);
+    let mut d: u64 = 0;
+    unsafe { check(cnt_hamming(a.as_ptr(), b.as_ptr(), len, &mut d)) };
+    d
+}
+
+/// A<->T, C<->G on the packed words; unused high bits of the last word stay zero.
+pub fn complement_hip(bits: &[u64], len: usize) -> Vec<u64> {
+    need(bits, len);
+    let words = unsafe { cnt_words_for(len) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    unsafe {
+        check(cnt_complement(bits.as_ptr(), len, res.as_mut_ptr()));
+        res.set_len(words);
+    }
+    res
+}
+
+/// `out(i) = complement(in(len - 1 - i))`.
+pub fn reverse_complement_hip(bits: &[u64], len: usize) -> Vec<u64> {
+    need(bits, len);
+    let words = unsafe { cnt_words_for(len) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    unsafe {
+        check(cnt_reverse_complement(bits.as_ptr(), len, res.as_mut_ptr()));
+        res.set_len(words);
+    }
+    res
+}
+
+/// Number of bytes outside `ACGTUacgtu` (with `allow_n` also `N`/`n` are legal); 0 = a valid sequence.
+pub fn validate_hip(n: &[u8], allow_n: bool) -> u64 {
+    let mut bad: u64 = 0;
+    unsafe { check(cnt_validate(n.as_ptr(), n.len(), if allow_n { 2 } else { 0 }, &mut bad)) };
+    bad
+}
+
 // ---- device-resident tier: data already in HBM (what the roofline numbers measure) ------------------
 
 /// Number of packed words for `n_len` nucleotides (`ceil(n_len / 32)`, n_to_bits.rs:35).
@@ -243,6 +296,17 @@ mod tests {
     fn test_n_to_bits2_hip() {
         assert_eq!(n_to_bits2_hip(b"ATCGNATCGNATCGNATCGNATCGNATCGNATCGN"), vec![0x36A45D1F46D48BA3u64, 0x5D1F4]);
         assert_eq!(n_to_bits2_hip(b"ATCGN"), vec![0b101110100011]);
+    }
+
+    #[test]
+    fn test_packed_ops() {
+        let x = n_to_bits_hip(b"ATCGATCG");
+        assert_eq!(hamming_hip(&x, &x, 8), 0);
+        assert_eq!(hamming_hip(&x, &complement_hip(&x, 8), 8), 8);
+        assert_eq!(bits_to_n_hip(&complement_hip(&x, 8), 8), b"TAGCTAGC".to_vec());
+        assert_eq!(bits_to_n_hip(&reverse_complement_hip(&x, 8), 8), b"CGATCGAT".to_vec());
+        assert_eq!(validate_hip(b"ACGTN", false), 1);
+        assert_eq!(validate_hip(b"ACGTN", true), 0);
     }
 
     #[test]

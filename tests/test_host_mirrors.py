@@ -49,3 +49,27 @@ def test_rust_binding_matches_the_header():
             assert is_ptr_c == is_ptr_r, (name, ca, ra)
             if is_ptr_c:
                 assert ("const" in ca) == ("*const" in ra), (name, ca, ra)
+
+
+def test_plain_c_program_links_and_runs():
+    """the boundary is a C ABI: tests/c_link_check.c (C11, gcc) links libcute_nt_hip.so and runs the device-free
+    entry points; on a box without a GPU the compute call answers CNT_ENODEV"""
+    import sys
+
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    sys.path.insert(0, ROOT)
+    from cute_nucleotides_amd import build
+
+    lib = build.build()
+    exe = os.path.join(ROOT, "tests", "c_link_check")
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-pedantic", "-o", exe, os.path.join(ROOT, "tests", "c_link_check.c"),
+                        "-L" + os.path.dirname(lib), "-lcute_nt_hip", "-Wl,-rpath," + os.path.dirname(lib)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    try:
+        run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, (run.returncode, run.stdout, run.stderr[-500:])
+        assert "c link ok: abi 1" in run.stdout
+    finally:
+        os.remove(exe)
