@@ -6,7 +6,7 @@ configs[4] ("256 GiB encode chunk-sharded across 8 x MI355X, per-GPU and aggrega
 
     python bench/bench_sharded_dev.py                       # all visible devices, 2^35 nt each (32 GiB)
     python bench/bench_sharded_dev.py --ndev 8 --log2-nt 35 # 8 x 32 GiB = 256 GiB
-    CNT_SHARD_ALIAS_DEVICES=1 python bench/bench_sharded_dev.py --ndev 4 --log2-nt 30   # 1-GPU box: code path only
+    python bench/bench_sharded_dev.py --ndev 4 --log2-nt 30 --alias   # 1-GPU box: code path only (cnt_test_alias_devices)
 
 Prints one JSON line: per-shard device milliseconds (HIP events on each device's stream), per-GPU and aggregate
 Gnt/s (aggregate = all nucleotides / wall time of the call), the partition (cnt_shard_range) and each device's
@@ -32,12 +32,15 @@ ap.add_argument("--log2-nt", type=int, default=35, help="nucleotides per shard =
 ap.add_argument("--iters", type=int, default=8)
 ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
 ap.add_argument("--decode", action="store_true", help="also time the decode of the shards")
+ap.add_argument("--alias", action="store_true", help="TEST SUPPORT: fold more shards than visible devices onto the devices that exist")
 a = ap.parse_args()
 count = torch.cuda.device_count()
 ndev = a.ndev or count
-alias = os.environ.get("CNT_SHARD_ALIAS_DEVICES") == "1"
+alias = a.alias
 if ndev > count and not alias:
-    raise SystemExit("%d shards need %d devices (%d visible); CNT_SHARD_ALIAS_DEVICES=1 folds them for a code-path run" % (ndev, ndev, count))
+    raise SystemExit("%d shards need %d devices (%d visible); --alias folds them for a code-path run" % (ndev, ndev, count))
+if alias:
+    sharding.alias_devices(True)
 n_global = ndev << a.log2_nt
 parts = [sharding.shard_range_c(n_global, ndev, k) for k in range(ndev)]
 shards, outs = [], []

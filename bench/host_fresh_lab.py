@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Host tier into FRESH outputs (the literal `-> Vec<u8>` drop-in: the reference allocates inside the timed call,
+benches/bench_n_to_bits.rs:6-7) against reused outputs, under the library's environment knobs -- one child process
+per setting (the knobs are read once per process).
+
+    python bench/host_fresh_lab.py [--log2-nt 30] [--reps 8]
+
+Rows: ms per call and GiB/s of nucleotides for n_to_bits_hip / bits_to_n_hip with the output (a) reused, (b) a fresh
+numpy array per call (np.empty -> untouched pages, freed again after the call), (c) fresh and munmap'ed outside the
+timed region (the allocation's share alone)."""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SETTINGS = [
+    ("default (hugepage advice + prefault team of 8)", {}),
+    ("CNT_HOST_PREFAULT=0 (round 2: hugepage advice only)", {"CNT_HOST_PREFAULT": "0"}),
+    ("prefault team of 4", {"CNT_HOST_PREFAULT_THREADS": "4"}),
+    ("prefault team of 16", {"CNT_HOST_PREFAULT_THREADS": "16"}),
+    ("prefault team of 8, 8 copy threads", {"CNT_HOST_COPY_THREADS": "8"}),
+    ("no prefault, 8 copy threads", {"CNT_HOST_PREFAULT": "0", "CNT_HOST_COPY_THREADS": "8"}),
+    ("prefault team of 8, no hugepage advice", {"CNT_HOST_HUGEPAGE": "0"}),
+    ("neither (round 1)", {"CNT_HOST_HUGEPAGE": "0", "CNT_HOST_PREFAULT": "0"}),
+]
+
+
+def child(log2_nt, reps):
+    import numpy as np
+
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    m = 1 << log2_nt
+    words = m // 32
+    rng = np.random.default_rng(1)
+    n = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, m, dtype=np.uint8)]
+    bits = np.empty(words, dtype=np.uint64)
+    back = np.empty(m, dtype=np.uint8)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    assert L.cnt_n_to_bits(p(n), m, p(bits), words) == 0 and L.cnt_bits_to_n(p(bits), words, m, p(back)) == 0
+    assert np.array_equal(back, n)
+    keep = []
+
+    def timed(fn, reps):
+        fn()
+        keep.clear()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    def enc_fresh():
+        out = np.empty(words, dtype=np.uint64)
+        assert L.cnt_n_to_bits(p(n), m, p(out), words) == 0
+
+    def dec_fresh():
+        out = np.empty(m, dtype=np.uint8)
+        assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0
+
+    def enc_fresh_kept():
+        out = np.empty(words, dtype=np.uint64)
+        assert L.cnt_n_to_bits(p(n), m, p(out), words) == 0
+        keep.append(out)
+
+    def dec_fresh_kept():
+        out = np.empty(m, dtype=np.uint8)
+        assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0
+        keep.append(out)
+
+    rows = {}
+    for name, fn, r in (("n_to_bits_hip reused", lambda: L.cnt_n_to_bits(p(n), m, p(bits), words), reps),
+                        ("bits_to_n_hip reused", lambda: L.cnt_bits_to_n(p(bits), words, m, p(back)), reps),
+                        ("n_to_bits_hip fresh", enc_fresh, reps), ("bits_to_n_hip fresh", dec_fresh, reps),
+                        ("n_to_bits_hip fresh, freed later", enc_fresh_kept, min(reps, 4)),
+                        ("bits_to_n_hip fresh, freed later", dec_fresh_kept, min(reps, 4))):
+        dt = timed(fn, r)
+        rows[name] = {"ms": round(dt * 1e3, 3), "GiBs": round(m / dt / 2**30, 2)}
+    keep.clear()
+    out = np.empty(m, dtype=np.uint8)
+    assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0 and np.array_equal(out, n)  # a prefaulted call still decodes correctly
+    rows["fresh_over_reused"] = {"n_to_bits_hip": round(rows["n_to_bits_hip fresh"]["ms"] / rows["n_to_bits_hip reused"]["ms"], 3),
+                                 "bits_to_n_hip": round(rows["bits_to_n_hip fresh"]["ms"] / rows["bits_to_n_hip reused"]["ms"], 3)}
+    print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2-nt", type=int, default=30)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        child(a.log2_nt, a.reps)
+        sys.exit(0)
+    for name, env in SETTINGS:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--log2-nt", str(a.log2_nt), "--reps", str(a.reps)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        print(json.dumps({"setting": name, "env": env, "log2_nt": a.log2_nt, "rows": json.loads(line[-1]) if line else None,
+                          "error": None if line else r.stderr[-400:]}), flush=True)

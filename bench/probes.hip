@@ -128,7 +128,7 @@ namespace shipped {
 using namespace cnt;
 
 template <int BLOCK, int U, int LAUX>
-__global__ __launch_bounds__(BLOCK) void k_read(const uint8_t* __restrict__ in, uint8_t* __restrict__ sink, uint64_t n_tiles) {
+__global__ __launch_bounds__(BLOCK) void k_read(const uint8_t* __restrict__ in, uint8_t* __restrict__ sink, uint32_t n_tiles) {
     constexpr uint32_t TILE = BLOCK * U * 16;
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + (uint64_t)blockIdx.x * TILE, TILE);
     u32x4 acc = {0, 0, 0, 0};
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(BLOCK) void k_read(const uint8_t* __restrict__ in, 
     touch_residency_pad(n_tiles, acc.x);
 }
 template <int BLOCK, int U, int SAUX>
-__global__ __launch_bounds__(BLOCK) void k_write(uint8_t* __restrict__ out, uint64_t n_tiles) {
+__global__ __launch_bounds__(BLOCK) void k_write(uint8_t* __restrict__ out, uint32_t n_tiles) {
     constexpr uint32_t TILE = BLOCK * U * 16;
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + (uint64_t)blockIdx.x * TILE, TILE);
     const u32x4 v = {(uint32_t)blockIdx.x, threadIdx.x, 3u, 4u};
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(BLOCK) void k_write(uint8_t* __restrict__ out, uint
     touch_residency_pad(n_tiles, v.x);
 }
 template <int BLOCK, int U, int C, int LAUX, int SAUX>
-__global__ __launch_bounds__(BLOCK) void k_copy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+__global__ __launch_bounds__(BLOCK) void k_copy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t xs) {
     constexpr uint32_t TILE = BLOCK * U * 16;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE, TILE), rout = rsrc_of(out + t * TILE, TILE);
     u32x4 v[U];
 #pragma unroll
@@ -160,9 +160,9 @@ __global__ __launch_bounds__(BLOCK) void k_copy(const uint8_t* __restrict__ in, 
 }
 // encode's access shape without the arithmetic: 16 B in, 4 B out per lane and load
 template <int BLOCK, int U, int C, int LAUX, int SAUX>
-__global__ __launch_bounds__(BLOCK) void k_r4w1(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+__global__ __launch_bounds__(BLOCK) void k_r4w1(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t xs) {
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN), rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
     u32x4 v[U];
 #pragma unroll
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(BLOCK) void k_r4w1(const uint8_t* __restrict__ in, 
 }
 // decode's access shape without the arithmetic: 4 B in, 16 B out
 template <int BLOCK, int U, int C, int LAUX, int SAUX>
-__global__ __launch_bounds__(BLOCK) void k_r1w4(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+__global__ __launch_bounds__(BLOCK) void k_r1w4(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t xs) {
     constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN), rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
     uint32_t x[U];
 #pragma unroll
@@ -201,12 +201,13 @@ extern "C" int probe_shipped(int kind, const void* a, void* b, size_t bytes, voi
     uint8_t* pb = static_cast<uint8_t*>(b);
     if (bytes == 0 || (bytes & 16383) || bytes > ((size_t)1 << 35)) return 1;
     constexpr int kAll = kSC0 | kSC1 | kNT;
+    const uint32_t xs = chip_info().xcd_shift;
     switch (kind) {
-        case 0: { const uint64_t t = bytes / (1024 * 16); hipLaunchKernelGGL((shipped::k_read<1024, 1, kNT>), dim3((unsigned)t), dim3(1024), 0, s, pa, pb, t); break; }
-        case 1: { const uint64_t t = bytes / (256 * 16); hipLaunchKernelGGL((shipped::k_copy<256, 1, 1, kNT, kAll>), dim3((unsigned)t), dim3(256), 0, s, pa, pb, t); break; }
-        case 2: { const uint64_t t = bytes / (64 * 2 * 16); hipLaunchKernelGGL((shipped::k_r4w1<64, 2, 2, kNT, kAll>), dim3((unsigned)t), dim3(64), lds_for_cap(23), s, pa, pb, t); break; }
-        case 3: { const uint64_t t = bytes / (128 * 2 * 16); hipLaunchKernelGGL((shipped::k_r1w4<128, 2, 4, 0, kAll>), dim3((unsigned)t), dim3(128), lds_for_cap(13), s, pa, pb, t); break; }
-        case 4: { const uint64_t t = bytes / (256 * 16); hipLaunchKernelGGL((shipped::k_write<256, 1, kAll>), dim3((unsigned)t), dim3(256), 0, s, pb, t); break; }
+        case 0: { const uint32_t t = (uint32_t)(bytes / (1024 * 16)); hipLaunchKernelGGL((shipped::k_read<1024, 1, kNT>), dim3(t), dim3(1024), 0, s, pa, pb, t); break; }
+        case 1: { const uint32_t t = (uint32_t)(bytes / (256 * 16)); hipLaunchKernelGGL((shipped::k_copy<256, 1, 1, kNT, kAll>), dim3(t), dim3(256), 0, s, pa, pb, t, xs); break; }
+        case 2: { const uint32_t t = (uint32_t)(bytes / (64 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r4w1<64, 2, 2, kNT, kAll>), dim3(t), dim3(64), lds_for_cap(23), s, pa, pb, t, xs); break; }
+        case 3: { const uint32_t t = (uint32_t)(bytes / (128 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r1w4<128, 2, 4, 0, kAll>), dim3(t), dim3(128), lds_for_cap(13), s, pa, pb, t, xs); break; }
+        case 4: { const uint32_t t = (uint32_t)(bytes / (256 * 16)); hipLaunchKernelGGL((shipped::k_write<256, 1, kAll>), dim3(t), dim3(256), 0, s, pb, t); break; }
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libcute_nt_hip.so")
 
 CNT_OK, CNT_EINVAL, CNT_ECAP, CNT_ELEN, CNT_ENODEV, CNT_ERANGE = 0, 1, 2, 3, 4, 5
 CNT_STRICT_LUT = 0x1
+CNT_TAIL_LUT = 0x4
 
 _vp, _sz, _u64, _int, _uint = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint
 
@@ -30,8 +31,11 @@ SIGNATURES = {
     "cnt_n_to_bits_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
     "cnt_bits_to_n": (_int, [_vp, _sz, _sz, _vp]),
     "cnt_n_to_bits2": (_int, [_vp, _sz, _vp, _sz]),
+    "cnt_n_to_bits2_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
     "cnt_bits_to_n2": (_int, [_vp, _sz, _sz, _vp]),
     "cnt_n_to_bits_sharded": (_int, [_vp, _sz, _vp, _sz, _int]),
+    "cnt_n_to_bits_sharded_ex": (_int, [_vp, _sz, _vp, _sz, _int, _uint]),
+    "cnt_n_to_bits2_sharded_ex": (_int, [_vp, _sz, _vp, _sz, _int, _uint]),
     "cnt_bits_to_n_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
     "cnt_n_to_bits2_sharded": (_int, [_vp, _sz, _vp, _sz, _int]),
     "cnt_bits_to_n2_sharded": (_int, [_vp, _sz, _sz, _vp, _int]),
@@ -66,6 +70,8 @@ SIGNATURES = {
     "cnt_set_tuning": (_int, [ctypes.c_char_p, _int]),
     "cnt_get_tuning": (_int, [ctypes.c_char_p, ctypes.POINTER(_int)]),
     "cnt_tuning_name": (ctypes.c_char_p, [ctypes.c_char_p, _int]),
+    "cnt_chip_info": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "cnt_test_alias_devices": (_int, [_int]),
 }
 
 _lib = None

@@ -66,21 +66,26 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Block -> tile mapping.  Dispatch is observed (never relied on for
-// correctness) to place block b on XCD b%8; with C > 1 each XCD turn covers C
-// consecutive tiles, i.e. a C-tile contiguous piece per private L2.  Bijective
-// on [0, n_tiles): whole groups of 8*C tiles are permuted, the ragged rest is
-// left in place.
+// Block -> tile mapping.  Dispatch is observed (never relied on for correctness) to place block b on
+// XCD b % X, X = the XCD count of the device (hipDeviceAttributeNumberOfXccs, a power of two: 8 on an
+// MI355X in SPX mode, fewer in the partitioned modes; the launchers pass xs = log2 X, see chip_info()).
+// With C > 1 each XCD turn covers C consecutive tiles, i.e. a C-tile contiguous piece per private L2.
+// Bijective on [0, n_tiles): whole groups of X*C tiles are permuted, the ragged rest is left in place.
+// All 32-bit: one launch never has more than 2^31-1 threads, i.e. < 2^26 tiles (max_tiles_per_launch).
 template <int C>
-__device__ __forceinline__ uint64_t tile_of_block(uint64_t b, uint64_t n_tiles) {
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t n_tiles, uint32_t xs) {
     if constexpr (C == 1) {
         return b;
     } else {
-        constexpr uint64_t G = 8 * C;
-        const uint64_t g = b / G;
-        if ((g + 1) * G > n_tiles) return b;
-        const uint64_t r = b % G;
-        return g * G + (r % 8) * C + (r / 8);
+        static_assert(C == 2 || C == 4, "C is a power of two");
+        constexpr uint32_t cs = C == 2 ? 1 : 2;
+        const uint32_t gs = xs + cs;  // log2 of the group size X*C
+        const uint32_t g = b >> gs;
+        if (((g + 1) << gs) > n_tiles) return b;
+        // group base + (XCD slot x of the block) * C + (turn of that XCD inside the group); xs < gs, so b's low xs
+        // bits are the slot directly
+        const uint32_t x = b & ~(~0u << xs), turn = (b >> xs) & (uint32_t)(C - 1);
+        return (g << gs) + (x << cs) + turn;
     }
 }
 
@@ -139,16 +144,22 @@ __device__ __forceinline__ uint32_t enc16(u32x4 q) {
 // reference does with a carry-less multiply, n_to_bits.rs:357-365,381-384);
 // v_perm_b32 is then a 4-entry byte LUT: code -> "ACTG" (n_to_bits.rs:23-30).
 __device__ __forceinline__ uint32_t dec1(uint32_t b /* 0..255 */) {
+#ifdef CNT_DEC_SHIFT_OR  // round 1-2 form: two shift-ORs (4-5 VALU per packed byte incl. the byte extraction)
     uint32_t t = (b << 6) | b;
     uint32_t sel = ((t << 12) | t) & 0x03030303u;
+#else
+    // b * 0x41041 = b | b<<6 | b<<12 | b<<18 in ONE full-rate v_mul_u32_u24 (both factors < 2^24); with the byte
+    // extraction folded into the multiply's SDWA operand select that is 3 VALU per packed byte: mul, and, perm
+    uint32_t sel = __umul24(b, 0x41041u) & 0x03030303u;
+#endif
     return __builtin_amdgcn_perm(0u, 0x47544341u /* 'A','C','T','G' = bytes 0..3 */, sel);
 }
 
 __device__ __forceinline__ u32x4 dec4(uint32_t x) {  // 4 packed bytes -> 16 ASCII bytes
     u32x4 r;
     r.x = dec1(x & 0xFFu);
-    r.y = dec1(__builtin_amdgcn_ubfe(x, 8, 8));
-    r.z = dec1(__builtin_amdgcn_ubfe(x, 16, 8));
+    r.y = dec1((x >> 8) & 0xFFu);
+    r.z = dec1((x >> 16) & 0xFFu);
     r.w = dec1(x >> 24);
     return r;
 }
@@ -159,22 +170,99 @@ __device__ __forceinline__ u32x4 dec4(uint32_t x) {  // 4 packed bytes -> 16 ASC
 // (bench/tune_lab5.hip).  The kernels never use the memory; this never-taken store only
 // keeps the allocation attached to them.
 extern __shared__ uint32_t residency_pad[];
-__device__ __forceinline__ void touch_residency_pad(uint64_t n_tiles, uint32_t v) {
-    if (n_tiles == ~0ull) residency_pad[threadIdx.x] = v;
+__device__ __forceinline__ void touch_residency_pad(uint32_t n_tiles, uint32_t v) {
+    if (n_tiles == ~0u) residency_pad[threadIdx.x] = v;  // a launch has < 2^26 tiles
 }
 
 // ===========================================================================
+// EDGES.  What the tile kernels cannot take -- the head words a launcher peels to line-align the
+// stores, and the ragged end behind the last whole tile -- used to be one or two extra launches of
+// the generic kernels (~5 us each behind a 0.2 ms kernel at 1 GiB: 2.5 % at BASELINE.json's
+// configs[1] size).  They now ride in the SAME launch, in the same grid: the LAST `groups` workgroups
+// of the launch, after they have issued their own tile's stores, also run the byte-granular body over
+// the edge items (a wave-uniform scalar branch at the END of the kernel: nothing is added in front of
+// a tile's loads, and the edge struct's kernel arguments are only fetched by the workgroups that use
+// them -- a first version with extra workgroups and the branch at the top made every launch start
+// with two dependent kernarg fetches and cost an isolated 0.2 ms launch ~1 us).
+// ===========================================================================
+constexpr uint64_t kNoLutWord = ~0ull;
+
+// One output word from byte loads, any alignment, any length; zero-pads the last word
+// (n_to_bits.rs:35).  `lut` = BYTE_LUT semantics for THIS word (CNT_STRICT_LUT everywhere, or
+// CNT_TAIL_LUT on the final partial word -- where the reference's SIMD encoders call
+// n_to_bits_lut, n_to_bits.rs:109-111,160-162,201-203,253-255).
+__device__ __forceinline__ uint64_t encode_word_bytes(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t w, bool lut) {
+    const uint64_t i0 = w << 5;
+    uint64_t acc = 0;
+    const int m = (n_len - i0) < 32 ? (int)(n_len - i0) : 32;
+    for (int k = 0; k < m; k += 4) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j < m) x |= (uint32_t)n[i0 + k + j] << (8 * j);
+        // a byte that was never loaded is 0 -> code 0 in both modes
+        if (lut) x = strict_filter(x);
+        acc |= (uint64_t)__builtin_amdgcn_ubfe(enc_gather(x & 0x06060606u), 19, 8) << (2 * k);
+    }
+    return acc;
+}
+
+// words [0, head_words) and [tail_first, words) of an encode, all relative to the caller's pointers
+struct EncodeEdges {
+    const uint8_t* n;
+    uint64_t* out;
+    uint64_t n_len, head_words, tail_first, words;
+    uint64_t lut_from;  // words >= lut_from take BYTE_LUT semantics (kNoLutWord: none)
+    uint32_t groups;    // the last `groups` workgroups of the launch share the edge items (0: this launch has none)
+};
+template <bool STRICT>
+__device__ __forceinline__ void encode_edges(const EncodeEdges& e, uint64_t idx, uint64_t stride) {
+    const uint64_t items = e.head_words + (e.words - e.tail_first);
+    for (uint64_t i = idx; i < items; i += stride) {
+        const uint64_t w = i < e.head_words ? i : e.tail_first + (i - e.head_words);
+        e.out[w] = encode_word_bytes(e.n, e.n_len, w, STRICT || w >= e.lut_from);
+    }
+}
+inline uint64_t encode_edge_items(const EncodeEdges& e) { return e.head_words + (e.words - e.tail_first); }
+
+// nucleotides [0, head) and [tail_lo, len) of a decode, one thread per nucleotide (byte stores:
+// the head exists because the output pointer is NOT aligned)
+struct DecodeEdges {
+    const uint64_t* bits;
+    uint8_t* out;
+    uint64_t head, tail_lo, len;
+    uint32_t groups;  // as in EncodeEdges
+};
+__device__ __forceinline__ void decode_edges(const DecodeEdges& e, uint64_t idx, uint64_t stride) {
+    const uint64_t items = e.head + (e.len - e.tail_lo);
+    for (uint64_t k = idx; k < items; k += stride) {
+        const uint64_t i = k < e.head ? k : e.tail_lo + (k - e.head);
+        const uint32_t code = (uint32_t)(e.bits[i >> 5] >> ((i & 31) << 1)) & 3u;
+        e.out[i] = (uint8_t)(0x47544341u >> (code << 3));  // "ACTG"[code], n_to_bits.rs:23-30
+    }
+}
+inline uint64_t decode_edge_items(const DecodeEdges& e) { return e.head + (e.len - e.tail_lo); }
+
+// the end of every tile kernel: the launch's last e.groups workgroups (groups <= n_tiles) share the edge items
+#define CNT_ENCODE_EDGES_TAIL(BLOCK_)                                                                                   \
+    if (blockIdx.x + e.groups >= n_tiles)                                                                               \
+        encode_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * (BLOCK_) + threadIdx.x, (uint64_t)e.groups * (BLOCK_));
+#define CNT_DECODE_EDGES_TAIL(BLOCK_)                                                                                   \
+    if (blockIdx.x + e.groups >= n_tiles)                                                                               \
+        decode_edges(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * (BLOCK_) + threadIdx.x, (uint64_t)e.groups * (BLOCK_));
+
+// ===========================================================================
 // ENCODE.  One workgroup = one tile of BLOCK*U*16 nt, no loop: the launch has one
-// workgroup per whole tile; the ragged remainder goes to n_to_bits_generic.
+// workgroup per whole tile plus the edge workgroups above.
 // ===========================================================================
 
 // STREAM: 16-B loads (1 KiB per wave-instruction, coalesced) -> one packed dword
 // per lane per load, stored 4 B per lane (256 B per wave-instruction).
 template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                          uint64_t n_tiles) {
+                                                          uint32_t n_tiles, uint32_t xs, EncodeEdges e) {
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
     const uint32_t tid = threadIdx.x;
@@ -186,6 +274,7 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b32(enc16<STRICT>(v[u]), rout, (u * BLOCK + tid) * 4, 0, SAUX);
+    CNT_ENCODE_EDGES_TAIL(BLOCK)
 }
 
 // WINDOW: variant 0's shape (one wave, 2 KiB in, 512 B out) for an input that starts at ANY
@@ -202,9 +291,9 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
 // the stores are line-aligned and hands the resulting input phase here.)
 template <int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                          uint64_t n_tiles, uint32_t phase) {
+                                                          uint32_t n_tiles, uint32_t phase, uint32_t xs, EncodeEdges e) {
     constexpr uint32_t TILE_IN = kWave * 2 * 16, TILE_OUT = TILE_IN / 4, SLACK = 144;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + SLACK);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
     const uint32_t lane = threadIdx.x;
@@ -223,6 +312,7 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
     const uint32_t o1 = __builtin_amdgcn_alignbit(residency_pad[kWave + lane + q + 1], residency_pad[kWave + lane + q], sh);
     __builtin_amdgcn_raw_buffer_store_b32(o0, rout, lane * 4, 0, SAUX);
     __builtin_amdgcn_raw_buffer_store_b32(o1, rout, (kWave + lane) * 4, 0, SAUX);
+    CNT_ENCODE_EDGES_TAIL(kWave)
 }
 
 // FUSED round trip (BASELINE.json configs[3]): one pass that reads the ASCII once and writes BOTH the
@@ -232,9 +322,9 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
 // per lane, 4 KiB of ASCII per workgroup, plain dispatch order (codec2_launch.hpp, bench/tune_lab11.hip).
 template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed,
-                                                           uint8_t* __restrict__ back, uint64_t n_tiles) {
+                                                           uint8_t* __restrict__ back, uint32_t n_tiles, uint32_t xs) {
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_PK = TILE_IN / 4;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
     const __amdgpu_buffer_rsrc_t rpk = rsrc_of(packed + t * TILE_PK, TILE_PK);
     const __amdgpu_buffer_rsrc_t rbk = rsrc_of(back + t * TILE_IN, TILE_IN);
@@ -258,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __rest
 // stores U/4 coalesced 16-B vectors.  No block barrier: the slab is per wave.
 template <int BLOCK, int U, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void n_to_bits_lds(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                       uint64_t n_tiles) {
+                                                       uint32_t n_tiles, EncodeEdges e) {
     static_assert(U % 4 == 0, "U must be a multiple of 4");
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
     __shared__ __attribute__((aligned(16))) uint32_t slab[BLOCK * U];
@@ -279,30 +369,19 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_lds(const uint8_t* __restrict
         const u32x4 q = *reinterpret_cast<const u32x4*>(my + (j * kWave + lane) * 4);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, q), rout, (wave * U * kWave + (j * kWave + lane) * 4) * 4, 0, SAUX);
     }
+    CNT_ENCODE_EDGES_TAIL(BLOCK)
 }
 
-// Generic / tail: one thread per output word, byte loads, any alignment, any
-// length; zero-pads the last word (n_to_bits.rs:35).  first_word offsets both
-// the input (32*first_word) and the output.
+// Generic: one thread per output word, byte loads, any alignment, any length; zero-pads the last
+// word (n_to_bits.rs:35).  Small inputs and inputs shorter than one tile (everything else rides
+// in the tile kernels' edge workgroups).
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __restrict__ n, uint64_t n_len,
                                                             uint64_t* __restrict__ out, uint64_t first_word,
-                                                            uint64_t n_words) {
+                                                            uint64_t n_words, uint64_t lut_from) {
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words;
-         w += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t i0 = w << 5;
-        uint64_t acc = 0;
-        const int m = (n_len - i0) < 32 ? (int)(n_len - i0) : 32;
-        for (int k = 0; k < m; k += 4) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k + j < m) x |= (uint32_t)n[i0 + k + j] << (8 * j);
-            // a byte that was never loaded is 0 -> code 0 in both modes
-            acc |= (uint64_t)__builtin_amdgcn_ubfe(enc4<STRICT>(x), 19, 8) << (2 * k);
-        }
-        out[w] = acc;
-    }
+         w += (uint64_t)gridDim.x * kBlock)
+        out[w] = encode_word_bytes(n, n_len, w, STRICT || w >= lut_from);
 }
 
 // STAGED: the host tier's small-call path (csrc/host_tier.inc).  The kernel reads the shim's own PINNED
@@ -311,12 +390,16 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
 // together -- ONE PCIe round trip per thread, where the generic kernel's byte loads chain several
 // (bench/latency_lab.hip: 18.8 -> 15.7 us for a 40 000-nt call).  One thread per output word.
 template <bool STRICT>
-__global__ __launch_bounds__(kBlock) void n_to_bits_staged(const uint8_t* __restrict__ n, uint64_t* __restrict__ out, uint64_t n_words) {
+__global__ __launch_bounds__(kBlock) void n_to_bits_staged(const uint8_t* __restrict__ n, uint64_t* __restrict__ out, uint64_t n_words,
+                                                           uint64_t lut_from) {
     const uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x;
     if (w >= n_words) return;
     const u32x4* p = reinterpret_cast<const u32x4*>(n + 32 * w);
     const u32x4 a = p[0], b = p[1];
-    out[w] = (uint64_t)enc16<STRICT>(a) | ((uint64_t)enc16<STRICT>(b) << 32);
+    if (!STRICT && w >= lut_from)  // CNT_TAIL_LUT: the final partial word through BYTE_LUT (zero padding -> code 0 either way)
+        out[w] = (uint64_t)enc16<true>(a) | ((uint64_t)enc16<true>(b) << 32);
+    else
+        out[w] = (uint64_t)enc16<STRICT>(a) | ((uint64_t)enc16<STRICT>(b) << 32);
 }
 
 // ===========================================================================
@@ -327,9 +410,9 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_staged(const uint8_t* __rest
 // wave-instruction), both coalesced.
 template <int BLOCK, int U, int C, int LAUX, int SAUX>
 __global__ __launch_bounds__(BLOCK) void bits_to_n_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                          uint64_t n_tiles) {
+                                                          uint32_t n_tiles, uint32_t xs, DecodeEdges e) {
     constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
     const uint32_t tid = threadIdx.x;
@@ -340,6 +423,7 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_stream(const uint8_t* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
+    CNT_DECODE_EDGES_TAIL(BLOCK)
 }
 
 // SHIFTED: output tile-aligned, the packed stream entered at any even bit position.  `in` is
@@ -350,9 +434,9 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_stream(const uint8_t* __restr
 // the stores.
 template <int BLOCK, int U, int C, int LAUX, int SAUX>
 __global__ __launch_bounds__(BLOCK) void bits_to_n_shifted(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                           uint64_t n_tiles, uint32_t sh) {
+                                                           uint32_t n_tiles, uint32_t sh, uint32_t xs, DecodeEdges e) {
     constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + 4);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
     const uint32_t tid = threadIdx.x;
@@ -367,6 +451,7 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_shifted(const uint8_t* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
+    CNT_DECODE_EDGES_TAIL(BLOCK)
 }
 
 // LDS (measured alternative): each wave loads U/4 x 1 KiB of packed words as
@@ -374,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_shifted(const uint8_t* __rest
 // (u*64+lane) (ds_read_b32, conflict-free) and stores U coalesced 16-B vectors.
 template <int BLOCK, int U, int LAUX, int SAUX>
 __global__ __launch_bounds__(BLOCK) void bits_to_n_lds(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                       uint64_t n_tiles) {
+                                                       uint32_t n_tiles, DecodeEdges e) {
     static_assert(U % 4 == 0, "U must be a multiple of 4");
     constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
     __shared__ __attribute__((aligned(16))) uint32_t slab[BLOCK * U];
@@ -394,6 +479,7 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_lds(const uint8_t* __restrict
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(my[u * kWave + lane])), rout,
                                                ((wave * U + u) * kWave + lane) * 16, 0, SAUX);
+    CNT_DECODE_EDGES_TAIL(BLOCK)
 }
 
 // STAGED twin for the host tier's small-call path: one thread per packed word, 8-B load from the pinned staging
@@ -414,9 +500,9 @@ __global__ void raise_flag(uint32_t* flag, uint32_t value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Generic / tail: one thread per packed word, writes min(32, len - 32w) bytes
-// with byte stores; any alignment.  Bits beyond `len` are ignored
-// (n_to_bits.rs:60-65 stops at len).
+// Generic: one thread per packed word, writes min(32, len - 32w) bytes with byte stores; any
+// alignment.  Bits beyond `len` are ignored (n_to_bits.rs:60-65 stops at len).  Small inputs and
+// inputs shorter than one tile (everything else rides in the tile kernels' edge workgroups).
 __global__ __launch_bounds__(kBlock) void bits_to_n_generic(const uint64_t* __restrict__ bits, uint64_t len,
                                                             uint8_t* __restrict__ out, uint64_t first_word,
                                                             uint64_t n_words) {
@@ -431,16 +517,6 @@ __global__ __launch_bounds__(kBlock) void bits_to_n_generic(const uint64_t* __re
             for (int j = 0; j < 4; ++j)
                 if (k + j < m) out[i0 + k + j] = (uint8_t)(d >> (8 * j));
         }
-    }
-}
-
-// Nucleotide range [lo, hi) of a decode, one thread per nucleotide: the head a launcher peels
-// to line-align the stores of the tile kernels, and the ragged end behind them.
-__global__ __launch_bounds__(kBlock) void bits_to_n_range(const uint64_t* __restrict__ bits, uint8_t* __restrict__ out,
-                                                          uint64_t lo, uint64_t hi) {
-    for (uint64_t i = lo + blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t code = (uint32_t)(bits[i >> 5] >> ((i & 31) << 1)) & 3u;
-        out[i] = (uint8_t)(0x47544341u >> (code << 3));  // "ACTG"[code], n_to_bits.rs:23-30
     }
 }
 

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "codec2_kernels.hpp"
 
 namespace cnt {
@@ -19,8 +21,45 @@ struct VariantDesc {
     uint32_t wg_cap;   // resident workgroups per CU to aim for via a dummy LDS allocation (0 = no cap)
 };
 
-// dynamic-LDS bytes that let `cap` workgroups (and no more) fit in a CU's 160 KiB
-inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (163840u / cap) / 256u * 256u : 0u; }
+// What the launch geometry depends on, asked of the device instead of assumed (an MI355X in SPX mode answers
+// 256 CUs / 160 KiB of LDS per CU / 8 XCDs; the CPX / DPX / QPX partition modes, or another CDNA part, do not):
+//   cus         multiProcessorCount                  -> grid of the persistent reductions
+//   lds_per_cu  maxSharedMemoryPerMultiProcessor     -> the dummy-LDS residency caps
+//   xcd_shift   log2(hipDeviceAttributeNumberOfXccs) -> the XCD-aware block -> tile maps (0 = identity map when the
+//               count is unknown or not a power of two)
+// Cached per device index; correctness never depends on any of it.
+struct ChipInfo {
+    uint32_t cus, lds_per_cu, xcds, xcd_shift;
+};
+inline ChipInfo query_chip(int device) {
+    ChipInfo c{0, 0, 0, 0};
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c.cus = (uint32_t)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && v > 0) c.lds_per_cu = (uint32_t)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && v > 0) c.xcds = (uint32_t)v;
+    (void)hipGetLastError();
+    if (!c.cus) c.cus = 1;
+    if (c.lds_per_cu < 65536u) c.lds_per_cu = 65536u;  // every CDNA CU has at least 64 KiB; a smaller answer is a per-block limit
+    if (!c.xcds) c.xcds = 1;
+    if ((c.xcds & (c.xcds - 1)) == 0)
+        while ((1u << c.xcd_shift) < c.xcds) ++c.xcd_shift;
+    return c;
+}
+inline const ChipInfo& chip_info() {  // of the calling thread's current device
+    constexpr int kMaxDev = 64;
+    static ChipInfo table[kMaxDev];
+    static std::atomic<uint8_t> ready[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    if (!ready[dev].load(std::memory_order_acquire)) {
+        table[dev] = query_chip(dev);  // racing threads write the same answer
+        ready[dev].store(1, std::memory_order_release);
+    }
+    return table[dev];
+}
+
+// dynamic-LDS bytes that let `cap` workgroups (and no more) fit in a CU's LDS (160 KiB on gfx950)
+inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (chip_info().lds_per_cu / cap) / 256u * 256u : 0u; }
 
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
@@ -38,6 +77,10 @@ constexpr VariantDesc kEncodeVariants[] = {
     {"stream B=64 U=2 xcd-pairs ld=nt st=sc1, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 11: as 0 with write-through-only stores
     {"stream B=64 U=2 xcd-pairs ld=sc0|nt st=sc1, 22 wg/CU", 64 * 2 * 16, 64, 22},  // 12
     {"stream B=64 U=2 xcd-pairs ld=sc0|nt st=sc0|sc1|nt, 22 wg/CU", 64 * 2 * 16, 64, 22},  // 13
+    // round 3: device-scope loads (sc1: do not allocate in the CU's vector L1) -- what moved decode by ~1 % (its variant 20)
+    {"stream B=64 U=2 xcd-pairs ld=sc1|nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 14
+    {"stream B=64 U=2 xcd-pairs ld=sc1 st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},     // 15
+    {"stream B=64 U=2 xcd-pairs ld=sc0|sc1|nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 16
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -48,30 +91,45 @@ inline unsigned grid_of(uint64_t n_tiles) { return (unsigned)(n_tiles > 0x7FFFFF
 // 64 = 2^31 threads.  Large buffers are therefore cut into several launches of at
 // most this many tiles (a multiple of 64, so every XCD-group permutation stays whole).
 inline uint64_t max_tiles_per_launch(int block) { return ((0x7FFFFFFFull / (uint64_t)block) / 64) * 64; }
+// how many of a launch's last workgroups share the edge items (one item per thread when there are enough tiles; the
+// edge bodies are strided loops, so any count >= 1 covers all items)
+constexpr unsigned kMaxEdgeGroups = 64;
+inline uint32_t edge_groups(uint64_t items, unsigned block, uint64_t n_tiles) {
+    uint64_t g = (items + block - 1) / block;
+    if (g > kMaxEdgeGroups) g = kMaxEdgeGroups;
+    if (g > n_tiles) g = n_tiles;
+    return (uint32_t)g;
+}
 
-// Launches the whole-tile part of an encode; *done_nt = nucleotides covered (a multiple of
-// the variant's tile).  d_n must be 16-B aligned, d_out 4-B (16-B for the lds variant).  Returns 0 / 1 (bad variant).
+// Launches an encode: the whole tiles of [d_n, d_n + n_len) plus, in the same (last) launch, the edge words `e`
+// describes (head words in front of d_n, ragged end behind the last tile).  *done_nt = nucleotides the tiles cover
+// (a multiple of the variant's tile); when that is 0 NOTHING is launched and the caller runs the generic kernel.
+// d_n must be 16-B aligned, d_out 4-B (16-B for the lds variant).  Returns 0 / 1 (bad variant).
 template <bool STRICT>
-int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_nt) {
+int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, EncodeEdges e, hipStream_t s, uint64_t* done_nt) {
     if (variant < 0 || variant >= kNumEncodeVariants) return 1;
     const uint64_t tile = kEncodeVariants[variant].tile_nt;
     const uint64_t total_tiles = n_len / tile;
     *done_nt = total_tiles * tile;
+    e.tail_first = e.head_words + (*done_nt >> 5);
     const uint64_t per_launch = max_tiles_per_launch(kEncodeVariants[variant].block);
+    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t lds = lds_for_cap(kEncodeVariants[variant].wg_cap);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
     const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+    const bool last = first + n_tiles == total_tiles;
     const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile;
     uint8_t* out = static_cast<uint8_t*>(d_out) + first * (tile / 4);
+    e.groups = last ? edge_groups(encode_edge_items(e), kEncodeVariants[variant].block, n_tiles) : 0u;  // the edges ride in the last launch
     const dim3 g(grid_of(n_tiles));
-    const uint32_t lds = lds_for_cap(kEncodeVariants[variant].wg_cap);
 #define CNT_ENC_STREAM(B, U, C, L, S) \
-    hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, n_tiles)
+    hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     switch (variant) {
         case 0: CNT_ENC_STREAM(64, 2, 2, kNT, kSC0 | kSC1 | kNT); break;
         case 1: CNT_ENC_STREAM(256, 1, 1, kNT, kSC1); break;
         case 2: CNT_ENC_STREAM(512, 1, 1, kSC0 | kNT, kSC1); break;
         case 3: CNT_ENC_STREAM(256, 4, 1, kNT, kNT); break;
-        case 4: hipLaunchKernelGGL((n_to_bits_lds<256, 4, kNT, kSC1, STRICT>), g, dim3(256), 0, s, in, out, n_tiles); break;
+        case 4: hipLaunchKernelGGL((n_to_bits_lds<256, 4, kNT, kSC1, STRICT>), g, dim3(256), 0, s, in, out, (uint32_t)n_tiles, e); break;
         case 5: CNT_ENC_STREAM(64, 2, 1, kNT, kSC1); break;
         case 6: CNT_ENC_STREAM(128, 2, 1, kNT, kSC1); break;
         case 7: CNT_ENC_STREAM(64, 2, 4, kNT, kSC1); break;
@@ -81,6 +139,9 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
         case 11: CNT_ENC_STREAM(64, 2, 2, kNT, kSC1); break;
         case 12: CNT_ENC_STREAM(64, 2, 2, kSC0 | kNT, kSC1); break;
         case 13: CNT_ENC_STREAM(64, 2, 2, kSC0 | kNT, kSC0 | kSC1 | kNT); break;
+        case 14: CNT_ENC_STREAM(64, 2, 2, kSC1 | kNT, kSC0 | kSC1 | kNT); break;
+        case 15: CNT_ENC_STREAM(64, 2, 2, kSC1, kSC0 | kSC1 | kNT); break;
+        case 16: CNT_ENC_STREAM(64, 2, 2, kSC0 | kSC1 | kNT, kSC0 | kSC1 | kNT); break;
         default: return 1;
     }
     }
@@ -93,13 +154,16 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, hip
 constexpr uint32_t kWindowEncodeTile = 64 * 2 * 16;
 constexpr uint32_t kWindowEncodeSlack = 144;  // bytes a tile may read behind its end
 template <bool STRICT>
-void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
+void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64);
     const uint32_t lds = lds_for_cap(23);  // doubles as the kernel's 768-B exchange slab
+    const uint32_t xs = chip_info().xcd_shift;
+    e.tail_first = e.head_words + total_tiles * (kWindowEncodeTile / 32);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        e.groups = first + n_tiles == total_tiles ? edge_groups(encode_edge_items(e), 64, n_tiles) : 0u;
         hipLaunchKernelGGL((n_to_bits_window<2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
-                           base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), n_tiles, phase);
+                           base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e);
     }
 }
 
@@ -119,15 +183,16 @@ template <bool STRICT>
 void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 2;  // in 4-KiB units, valid for both shapes
     const uint32_t lds = lds_for_cap(cap);
+    const uint32_t xs = chip_info().xcd_shift;
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         const uint8_t* i0 = in + first * kRoundTripTile;
         uint8_t* p0 = packed + first * (kRoundTripTile / 4);
         uint8_t* b0 = back + first * kRoundTripTile;
         if (shape == 1)
-            hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(2 * n_tiles)), dim3(64), lds, s, i0, p0, b0, 2 * n_tiles);
+            hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(2 * n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)(2 * n_tiles), xs);
         else
-            hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, n_tiles);
+            hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs);
     }
 }
 
@@ -151,30 +216,47 @@ constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=128 U=2 xcd-pairs ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 15: the default before the XCD group size was re-swept
     {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 14 wg/CU", 128 * 2 * 16, 128, 14},  // 16
     {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 15 wg/CU", 128 * 2 * 16, 128, 15},  // 17
+    // round 3: one 4-KiB output page per FOUR-wave workgroup under the equivalent residency
+    // (13 two-wave workgroups = 26 waves; here 6 / 7 four-wave workgroups), and the load policies not yet tried under the quad map
+    {"stream B=256 U=1 xcd-quads ld=plain st=sc0|sc1|nt, 6 wg/CU", 256 * 1 * 16, 256, 6},    // 18
+    {"stream B=256 U=1 xcd-quads ld=plain st=sc0|sc1|nt, 7 wg/CU", 256 * 1 * 16, 256, 7},    // 19
+    {"stream B=128 U=2 xcd-quads ld=sc1 st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},    // 20
+    {"stream B=128 U=2 xcd-quads ld=nt st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},     // 21
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 12 wg/CU", 128 * 2 * 16, 128, 12},  // 22
+    {"stream B=128 U=2 xcd-quads ld=sc1|nt st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},   // 23
+    {"stream B=128 U=2 xcd-quads ld=sc0|sc1 st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 24
+    {"stream B=128 U=2 xcd-quads ld=sc1 st=sc0|sc1|nt, 14 wg/CU", 128 * 2 * 16, 128, 14},      // 25
+    {"stream B=128 U=2 xcd-quads ld=sc1 st=sc0|sc1|nt, 12 wg/CU", 128 * 2 * 16, 128, 12},      // 26
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
-inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_nt) {
+// As launch_encode: whole tiles of the output [d_out, d_out + len) plus, riding in the last launch, the edge
+// nucleotides `e` describes; *done_nt == 0 means nothing was launched.
+inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t len, DecodeEdges e, hipStream_t s, uint64_t* done_nt) {
     if (variant < 0 || variant >= kNumDecodeVariants) return 1;
     const uint64_t tile = kDecodeVariants[variant].tile_nt;
     const uint64_t total_tiles = len / tile;
     *done_nt = total_tiles * tile;
+    e.tail_lo = e.head + *done_nt;
     const uint64_t per_launch = max_tiles_per_launch(kDecodeVariants[variant].block);
+    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t lds = lds_for_cap(kDecodeVariants[variant].wg_cap);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
     const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+    const bool last = first + n_tiles == total_tiles;
     const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * (tile / 4);
     uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile;
+    e.groups = last ? edge_groups(decode_edge_items(e), kDecodeVariants[variant].block, n_tiles) : 0u;
     const dim3 g(grid_of(n_tiles));
     constexpr int kAll = kSC0 | kSC1 | kNT;
-    const uint32_t lds = lds_for_cap(kDecodeVariants[variant].wg_cap);
 #define CNT_DEC_STREAM(B, U, C, L, S) \
-    hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), lds, s, in, out, n_tiles)
+    hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     switch (variant) {
         case 0: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
         case 1: CNT_DEC_STREAM(256, 2, 1, 0, kAll); break;
         case 2: CNT_DEC_STREAM(64, 2, 2, 0, kAll); break;
         case 3: CNT_DEC_STREAM(256, 2, 1, kNT, kNT); break;
-        case 4: hipLaunchKernelGGL((bits_to_n_lds<256, 4, kNT, kAll>), g, dim3(256), 0, s, in, out, n_tiles); break;
+        case 4: hipLaunchKernelGGL((bits_to_n_lds<256, 4, kNT, kAll>), g, dim3(256), 0, s, in, out, (uint32_t)n_tiles, e); break;
         case 5: CNT_DEC_STREAM(128, 2, 2, 0, kAll); break;
         case 6: CNT_DEC_STREAM(128, 2, 1, kNT, kAll); break;
         case 7: CNT_DEC_STREAM(128, 2, 1, 0, kSC1 | kNT); break;
@@ -186,7 +268,12 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 13: CNT_DEC_STREAM(128, 2, 2, 0, kSC1 | kNT); break;
         case 14: CNT_DEC_STREAM(128, 2, 2, kSC1, kAll); break;
         case 15: CNT_DEC_STREAM(128, 2, 2, 0, kAll); break;
-        case 16: case 17: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
+        case 16: case 17: case 22: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
+        case 18: case 19: CNT_DEC_STREAM(256, 1, 4, 0, kAll); break;
+        case 20: case 25: case 26: CNT_DEC_STREAM(128, 2, 4, kSC1, kAll); break;
+        case 23: CNT_DEC_STREAM(128, 2, 4, kSC1 | kNT, kAll); break;
+        case 24: CNT_DEC_STREAM(128, 2, 4, kSC0 | kSC1, kAll); break;
+        case 21: CNT_DEC_STREAM(128, 2, 4, kNT, kAll); break;
         default: return 1;
     }
     }
@@ -197,13 +284,16 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
 // The any-alignment companion of decode variant 0: `in` = the dword holding the first
 // nucleotide, `sh` = 2 * (its index among that dword's 16).
 constexpr uint32_t kShiftedDecodeTile = 128 * 2 * 16;
-inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
+inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, DecodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(128);
     const uint32_t lds = lds_for_cap(13);
+    const uint32_t xs = chip_info().xcd_shift;
+    e.tail_lo = e.head + total_tiles * kShiftedDecodeTile;
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        e.groups = first + n_tiles == total_tiles ? edge_groups(decode_edge_items(e), 128, n_tiles) : 0u;
         hipLaunchKernelGGL((bits_to_n_shifted<128, 2, 4, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(128), lds, s,
-                           in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, n_tiles, sh);
+                           in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, (uint32_t)n_tiles, sh, xs, e);
     }
 }
 

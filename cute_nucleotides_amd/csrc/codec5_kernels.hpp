@@ -171,14 +171,17 @@ __device__ __forceinline__ void decode27(uint32_t lo, uint32_t hi, uint32_t (&b)
 // ---------------------------------------------------------------------------
 // Generic kernels: one thread per word, byte accesses, any alignment/length.
 // ---------------------------------------------------------------------------
+// lut_from: words >= lut_from take BYTE_LUT semantics (CNT_TAIL_LUT: where n_to_bits2_pext hands over to
+// n_to_bits2_lut, n_to_bits2.rs:120,179-185); kNoLutWord = none.
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits2_generic(const uint8_t* __restrict__ n, uint64_t n_len,
                                                              uint64_t* __restrict__ out, uint64_t first_word,
-                                                             uint64_t n_words) {
+                                                             uint64_t n_words, uint64_t lut_from) {
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words;
          w += (uint64_t)gridDim.x * kBlock) {
         const uint64_t i0 = w * 27;
         const int m = (n_len - i0) < 27 ? (int)(n_len - i0) : 27;
+        const bool lut = STRICT || w >= lut_from;
         uint32_t c[7];
 #pragma unroll
         for (int d = 0; d < 7; ++d) {
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits2_generic(const uint8_t* __re
                 const int k = 4 * d + j;
                 if (k < 27 && k < m) x |= (uint32_t)n[i0 + k] << (8 * j);
             }
-            c[d] = code5<STRICT>(x);  // unloaded bytes are 0 -> code 0 (missing digits = 0, n_to_bits2.rs:58-70)
+            c[d] = lut ? code5_strict(x) : code5_fast(x);  // unloaded bytes are 0 -> code 0 (missing digits = 0, n_to_bits2.rs:58-70)
         }
         out[w] = pack27(c);
     }
@@ -260,14 +263,14 @@ __device__ __forceinline__ uint64_t word_from_slab(const uint32_t* my, uint32_t 
 // 512 B per wave-instruction).
 template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
 __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                               uint64_t n_wave_tiles) {
+                                                               uint64_t n_wave_tiles, uint32_t xs) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
     // access whose descriptor depends on it in a waterfall loop (v_readfirstlane / s_and_saveexec)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // C > 1 (single-wave workgroups only): XCD-pair tile map, see tile_of_block
-    const uint64_t t = C > 1 ? tile_of_block<C>(blockIdx.x, n_wave_tiles) : blockIdx.x * (uint64_t)WAVES + wave;
+    const uint64_t t = C > 1 ? tile_of_block<C>(blockIdx.x, (uint32_t)n_wave_tiles, xs) : blockIdx.x * (uint64_t)WAVES + wave;
     if (t >= n_wave_tiles) return;  // wave-uniform
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, TILE_BYTES);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
@@ -302,11 +305,11 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 // offset into it.  Reads up to 127 B before and 128 B behind the tile (launcher's business).
 template <int LAUX, int SAUX, bool STRICT, int C>
 __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                        uint64_t n_wave_tiles, uint32_t phase) {
+                                                        uint64_t n_wave_tiles, uint32_t phase, uint32_t xs) {
     constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, WIN_VECS = kWaveVecs5 * WPL + 8;
     __shared__ __attribute__((aligned(16))) uint32_t my[WIN_VECS * 4 + 4];
     const uint32_t lane = threadIdx.x;
-    const uint64_t t = tile_of_block<C>(blockIdx.x, n_wave_tiles);
+    const uint64_t t = tile_of_block<C>(blockIdx.x, (uint32_t)n_wave_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, WIN_VECS * 16);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
     constexpr int NLD = (WIN_VECS + 63) / 64;
@@ -338,14 +341,14 @@ __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restric
 // with WPL*108 coalesced 16-B stores.
 template <int WAVES, int WPL, int LAUX, int SAUX, int C = 1>
 __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                               uint64_t n_wave_tiles) {
+                                                               uint64_t n_wave_tiles, uint32_t xs) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
     // access whose descriptor depends on it in a waterfall loop (v_readfirstlane / s_and_saveexec)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // C > 1 (single-wave workgroups only): XCD-pair tile map, see tile_of_block
-    const uint64_t t = C > 1 ? tile_of_block<C>(blockIdx.x, n_wave_tiles) : blockIdx.x * (uint64_t)WAVES + wave;
+    const uint64_t t = C > 1 ? tile_of_block<C>(blockIdx.x, (uint32_t)n_wave_tiles, xs) : blockIdx.x * (uint64_t)WAVES + wave;
     if (t >= n_wave_tiles) return;  // wave-uniform
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * (TILE_WORDS * 8), TILE_WORDS * 8);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_BYTES, TILE_BYTES);

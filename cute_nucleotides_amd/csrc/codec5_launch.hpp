@@ -81,6 +81,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
     const uint64_t total = n_len / tile_nt;
     *done_words = total * tile_words;
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;  // wave tiles per launch (<= 2^31-1 threads)
+    const uint32_t xs = chip_info().xcd_shift;
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile_nt;
@@ -89,7 +90,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
         const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;
         const uint32_t lds = kEncode2Variants[variant].wg_cap ? lds_for_cap(kEncode2Variants[variant].wg_cap) - slab : 0u;
 #define CNT_ENC2(W, P, L, S) \
-    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
+    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs)
         switch (variant) {
             case 0: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 1: CNT_ENC2(1, 4, kNT, kSC1); break;
@@ -100,8 +101,8 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
             case 6: case 7: case 8: case 11: case 12: case 13: case 14: case 15: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 16: case 17: case 18: case 19: case 20: CNT_ENC2(1, 4, kNT, kSC1); break;
             case 21: CNT_ENC2(1, 4, kNT, kSC0 | kSC1 | kNT); break;
-            case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
-            case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
+            case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
             default: return 1;
         }
 #undef CNT_ENC2
@@ -116,11 +117,12 @@ constexpr uint32_t kWindowEncode2Slack = 128;             // bytes a tile may re
 template <bool STRICT>
 void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
+    const uint32_t xs = chip_info().xcd_shift;
     const uint32_t lds = lds_for_cap(kEncode2Variants[0].wg_cap) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         hipLaunchKernelGGL((n_to_bits2_window<kNT, kSC1, STRICT, 1>), dim3(grid_of(n)), dim3(64), lds, s,
-                           base + first * kWindowEncode2Tile, out + first * 1024, n, phase);
+                           base + first * kWindowEncode2Tile, out + first * 1024, n, phase, xs);
     }
 }
 
@@ -130,6 +132,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
     const uint64_t total = len / tile_nt;
     *done_words = total * tile_words;
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
+    const uint32_t xs = chip_info().xcd_shift;
     constexpr int kAll = kSC0 | kSC1 | kNT;
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
@@ -138,10 +141,10 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;  // static slab, see launch_encode2
         const uint32_t lds = kDecode2Variants[variant].wg_cap ? lds_for_cap(kDecode2Variants[variant].wg_cap) - slab : 0u;
 #define CNT_DEC2(W, P, L, S) \
-    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n)
+    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs)
         switch (variant) {
-            case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
-            case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
+            case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
             case 2: CNT_DEC2(2, 2, 0, kAll); break;
             case 3: CNT_DEC2(4, 2, 0, kAll); break;
@@ -150,8 +153,8 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
             case 9: case 13: case 14: case 15: CNT_DEC2(1, 2, 0, kAll); break;
             case 22: case 23: case 24: case 25: case 26: CNT_DEC2(1, 4, 0, kAll); break;
-            case 27: case 28: hipLaunchKernelGGL((bits_to_n2_wave<1, 4, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
-            case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n); break;
+            case 27: case 28: hipLaunchKernelGGL((bits_to_n2_wave<1, 4, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
+            case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
             default: return 1;
         }
 #undef CNT_DEC2

@@ -151,6 +151,7 @@ int cnt_device_numa_node(int device, int* node) {
 }
 
 static int release_thread_ctx() {
+    t_ctx.prefault.stop();
     t_ctx.pool.stop();
     for (auto& kv : t_ctx.per_device) kv.second.release();
     t_ctx.per_device.clear();
@@ -171,7 +172,7 @@ int cnt_shutdown(void) {
 
 // ---- host tier ----------------------------------------------------------------------
 int cnt_n_to_bits_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags) {
-    return host_encode(n, n_len, out, out_words, flags, 32, kChunkNt, encode_dev);
+    return host_encode(n, n_len, out, out_words, flags, lut_from_of(n_len, flags, 32), 32, kChunkNt, encode_impl);
 }
 int cnt_n_to_bits(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words) {
     return cnt_n_to_bits_ex(n, n_len, out, out_words, 0);
@@ -179,8 +180,11 @@ int cnt_n_to_bits(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_word
 int cnt_bits_to_n(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
     return host_decode(bits, words, len, out, 32, kChunkNt, decode_dev);
 }
+int cnt_n_to_bits2_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags) {
+    return host_encode(n, n_len, out, out_words, flags, lut_from_of(n_len, flags, 27), 27, kChunkNt5, encode2_impl);
+}
 int cnt_n_to_bits2(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words) {
-    return host_encode(n, n_len, out, out_words, 0, 27, kChunkNt5, encode2_dev);
+    return cnt_n_to_bits2_ex(n, n_len, out, out_words, 0);
 }
 int cnt_bits_to_n2(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
     return host_decode(bits, words, len, out, 27, kChunkNt5, decode2_dev);
@@ -188,15 +192,21 @@ int cnt_bits_to_n2(const uint64_t* bits, size_t words, size_t len, uint8_t* out)
 
 // ---- sharded tier -------------------------------------------------------------------
 // Partition: shard_range() above.  No collective: outputs are disjoint ranges of `out`.
+int cnt_n_to_bits_sharded_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev, unsigned flags) {
+    return sharded_host_encode(n, n_len, out, out_words, ndev, flags, 32, kChunkNt, encode_impl);
+}
 int cnt_n_to_bits_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev) {
-    return sharded_host_encode(n, n_len, out, out_words, ndev, 32, cnt_n_to_bits);
+    return cnt_n_to_bits_sharded_ex(n, n_len, out, out_words, ndev, 0);
 }
 int cnt_bits_to_n_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
     return sharded_host_decode(bits, words, len, out, ndev, 32, cnt_bits_to_n);
 }
 // 5-letter codec over N GPUs: same scheme, shards are whole numbers of 128-word tiles (3456 nt)
+int cnt_n_to_bits2_sharded_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev, unsigned flags) {
+    return sharded_host_encode(n, n_len, out, out_words, ndev, flags, 27, kChunkNt5, encode2_impl);
+}
 int cnt_n_to_bits2_sharded(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, int ndev) {
-    return sharded_host_encode(n, n_len, out, out_words, ndev, 27, cnt_n_to_bits2);
+    return cnt_n_to_bits2_sharded_ex(n, n_len, out, out_words, ndev, 0);
 }
 int cnt_bits_to_n2_sharded(const uint64_t* bits, size_t words, size_t len, uint8_t* out, int ndev) {
     return sharded_host_decode(bits, words, len, out, ndev, 27, cnt_bits_to_n2);
@@ -215,7 +225,7 @@ int cnt_shard_worker_info(int k, int* device, int* numa_node, int* n_cpus, int* 
 
 // device-resident shards: one entry per shard, shard k on device k (k % count under the test hook)
 static int sharded_dev_encode(const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, int ndev,
-                              unsigned flags, float* shard_ms, enc_fn fn) {
+                              unsigned flags, float* shard_ms, int (*fn)(const void*, size_t, void*, size_t, unsigned, hipStream_t)) {
     if (!d_n || !n_len || !d_out || !out_words) return CNT_EINVAL;
     return sharded_dev_run(ndev, shard_ms, [&](int k, hipStream_t s) { return fn(d_n[k], n_len[k], d_out[k], out_words[k], flags, s); });
 }
@@ -374,6 +384,18 @@ int cnt_get_tuning(const char* key, int* value) {
     else return CNT_EINVAL;
     return CNT_OK;
 }
+
+int cnt_chip_info(int device, int* compute_units, int* lds_bytes_per_cu, int* xcds) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CNT_ENODEV;
+    const ChipInfo c = query_chip(device);
+    if (compute_units) *compute_units = (int)c.cus;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)c.lds_per_cu;
+    if (xcds) *xcds = (int)c.xcds;
+    return CNT_OK;
+}
+
+int cnt_test_alias_devices(int on) { return g_alias_devices.exchange(on ? 1 : 0); }
 
 const char* cnt_tuning_name(const char* key, int value) {
     if (!key) return nullptr;

@@ -49,20 +49,20 @@ __device__ __forceinline__ uint64_t block_sum_to(uint64_t v, unsigned long long*
 }
 
 // Where the 16-B vector v of workgroup b's tile lives.  Linear: tile b, vector v.  XCD-interleaved
-// (XI): groups of 8 workgroups (one per XCD, block b runs on XCD b % 8) share a super-tile of 8 tiles
+// (XI): groups of X workgroups (one per XCD, block b runs on XCD b % X, X = 2^xs from chip_info()) share a super-tile of X tiles
 // and take its 4-KiB pages round-robin, so that at any time the eight XCDs read eight CONSECUTIVE
 // pages and each one whole pages -- the access pattern the codec kernels get from their small tiles
 // (codec2_kernels.hpp), here for 32-64 KiB reduction tiles.  Returns the byte offset from `base` and
 // sets `base_off` to the start of the descriptor window.
 template <uint32_t TILE, bool XI>
-__device__ __forceinline__ uint32_t vec_offset(uint64_t b, uint64_t n_tiles, uint32_t v, uint64_t& win_base, uint32_t& win_bytes) {
+__device__ __forceinline__ uint32_t vec_offset(uint64_t b, uint64_t n_tiles, uint32_t v, uint32_t xs, uint64_t& win_base, uint32_t& win_bytes) {
     if constexpr (XI) {
-        const uint64_t g = b >> 3;
-        if (((g + 1) << 3) <= n_tiles) {
-            win_base = g * 8ull * TILE;
-            win_bytes = 8u * TILE;
-            const uint32_t x = (uint32_t)(b & 7), page = v >> 8, off = v & 255u;
-            return ((page * 8u + x) << 12) + (off << 4);
+        const uint64_t g = b >> xs;
+        if (((g + 1) << xs) <= n_tiles) {
+            win_base = (g << xs) * (uint64_t)TILE;
+            win_bytes = TILE << xs;
+            const uint32_t x = (uint32_t)b & ((1u << xs) - 1u), page = v >> 8, off = v & 255u;
+            return (((page << xs) + x) << 12) + (off << 4);
         }
     }
     win_base = b * (uint64_t)TILE;
@@ -103,12 +103,12 @@ inline unsigned sum_partials_grid(uint64_t n) {
 
 template <int U, bool XI>
 __global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                                           uint64_t n_tiles, unsigned long long* __restrict__ partial) {
+                                                           uint64_t n_tiles, unsigned long long* __restrict__ partial, uint32_t xs) {
     constexpr uint32_t TILE = kRedBlock * U * 16;
     uint64_t wb;
     uint32_t wn, off[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) off[u] = vec_offset<TILE, XI>(blockIdx.x, n_tiles, u * kRedBlock + threadIdx.x, wb, wn);
+    for (int u = 0; u < U; ++u) off[u] = vec_offset<TILE, XI>(blockIdx.x, n_tiles, u * kRedBlock + threadIdx.x, xs, wb, wn);
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(a + wb, wn), rb = rsrc_of(b + wb, wn);
     u32x4 va[U], vb[U];
 #pragma unroll
@@ -142,7 +142,7 @@ __device__ __forceinline__ void wave_sum_to(uint64_t v, unsigned long long* dst)
 
 constexpr int kHammingRunKiB = 8, kHammingWavesPerCU = 2;     // bench/tune_lab15.hip
 constexpr int kValidateRunKiB = 16, kValidateWavesPerCU = 4;
-constexpr unsigned kCUs = 256;                                 // MI355X
+// the grid is min(n_runs, compute units x waves per CU); the CU count comes from chip_info() (codec2_launch.hpp)
 
 template <int RUN>
 __global__ __launch_bounds__(64) void hamming_persist(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t n_runs,
@@ -290,12 +290,12 @@ __device__ __forceinline__ uint32_t invalid_bytes32(uint32_t x) {
 
 template <int U, bool ALLOW_N, bool XI>
 __global__ __launch_bounds__(kRedBlock) void validate_tiles(const uint8_t* __restrict__ n, uint64_t n_tiles,
-                                                            unsigned long long* __restrict__ partial) {
+                                                            unsigned long long* __restrict__ partial, uint32_t xs) {
     constexpr uint32_t TILE = kRedBlock * U * 16;
     uint64_t wb;
     uint32_t wn, off[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) off[u] = vec_offset<TILE, XI>(blockIdx.x, n_tiles, u * kRedBlock + threadIdx.x, wb, wn);
+    for (int u = 0; u < U; ++u) off[u] = vec_offset<TILE, XI>(blockIdx.x, n_tiles, u * kRedBlock + threadIdx.x, xs, wb, wn);
     const __amdgpu_buffer_rsrc_t rn = rsrc_of(n + wb, wn);
     u32x4 v[U];
 #pragma unroll

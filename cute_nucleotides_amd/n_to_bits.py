@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import CNT_STRICT_LUT, check, lib
+from ._lib import CNT_STRICT_LUT, CNT_TAIL_LUT, check, lib
 
 
 def _u8(n):
@@ -39,16 +39,27 @@ def _p(a):
     return ctypes.c_void_p(a.ctypes.data if a.size else 0)
 
 
+def encode_flags(strict_lut=False, tail_lut=False):
+    """The C ABI's encode flags (include/cute_nt.h).  Which reference function each setting reproduces
+    on ARBITRARY bytes (on the alphabet ACGTUacgtu all of them agree):
+        default              (byte>>1)&3 everywhere
+        tail_lut=True        n_to_bits_{pext,shift,movemask,mul} exactly: bit extraction on whole
+                             32-nt blocks, BYTE_LUT on the final partial word (n_to_bits.rs:109-111)
+        strict_lut=True      n_to_bits_lut exactly: BYTE_LUT everywhere (n_to_bits.rs:8-21,34-47)"""
+    return (CNT_STRICT_LUT if strict_lut else 0) | (CNT_TAIL_LUT if tail_lut else 0)
+
+
 # ---- host tier ------------------------------------------------------------------------
-def n_to_bits_hip(n, strict_lut=False):
+def n_to_bits_hip(n, strict_lut=False, tail_lut=False):
     """Encode {A,T/U,C,G} -> {00,10,01,11}, 32 nt per u64, LSB first (n_to_bits.rs:34-47).
 
     Returns ceil(len/32) words; the unused high bits of the last word are zero.
     strict_lut=True gives n_to_bits_lut's table semantics on bytes outside the alphabet
-    (they encode as 0); the default is the SIMD variants' (byte>>1)&3."""
+    (they encode as 0); the default is the SIMD variants' (byte>>1)&3; tail_lut=True is the SIMD
+    variants to the letter (their ragged end goes through the table), see encode_flags."""
     n = _u8(n)
     out = np.empty(lib().cnt_words_for(n.size), dtype=np.uint64)
-    check(lib().cnt_n_to_bits_ex(_p(n), n.size, _p(out), out.size, CNT_STRICT_LUT if strict_lut else 0))
+    check(lib().cnt_n_to_bits_ex(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut)))
     return out
 
 
@@ -65,11 +76,11 @@ def bits_to_n_hip(bits, length):
     return out
 
 
-def n_to_bits_hip_sharded(n, ndev=0):
+def n_to_bits_hip_sharded(n, ndev=0, strict_lut=False, tail_lut=False):
     """n_to_bits_hip with the buffer cut into contiguous chunks over `ndev` GPUs (0 = all)."""
     n = _u8(n)
     out = np.empty(lib().cnt_words_for(n.size), dtype=np.uint64)
-    check(lib().cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, ndev))
+    check(lib().cnt_n_to_bits_sharded_ex(_p(n), n.size, _p(out), out.size, ndev, encode_flags(strict_lut, tail_lut)))
     return out
 
 
@@ -136,7 +147,7 @@ def words_for(n_len):
     return lib().cnt_words_for(n_len)
 
 
-def n_to_bits_dev(n, out=None, strict_lut=False):
+def n_to_bits_dev(n, out=None, strict_lut=False, tail_lut=False):
     """Device-resident encode: uint8 CUDA tensor [N] -> int64 CUDA tensor [ceil(N/32)]
     (bit pattern of the u64 words).  Enqueues on torch's current stream and returns."""
     torch = _dev_guard(n)
@@ -145,11 +156,11 @@ def n_to_bits_dev(n, out=None, strict_lut=False):
     words = lib().cnt_words_for(n.numel())
     out = _out_words(torch, out, words, n)
     _enqueue(n, lib().cnt_n_to_bits_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
-             out.numel(), CNT_STRICT_LUT if strict_lut else 0)
+             out.numel(), encode_flags(strict_lut, tail_lut))
     return out[:words]
 
 
-def round_trip_dev(n, out_bits=None, out_n=None, strict_lut=False):
+def round_trip_dev(n, out_bits=None, out_n=None, strict_lut=False, tail_lut=False):
     """Fused device-resident encode + decode: returns (packed words, canonical ASCII) of `n` in one
     pass over it (cnt_round_trip_dev)."""
     torch = _dev_guard(n)
@@ -159,7 +170,7 @@ def round_trip_dev(n, out_bits=None, out_n=None, strict_lut=False):
     out_bits = _out_words(torch, out_bits, words, n)
     out_n = _out_bytes(torch, out_n, n.numel(), n)
     _enqueue(n, lib().cnt_round_trip_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out_bits.data_ptr()),
-             out_bits.numel(), ctypes.c_void_p(out_n.data_ptr()), CNT_STRICT_LUT if strict_lut else 0)
+             out_bits.numel(), ctypes.c_void_p(out_n.data_ptr()), encode_flags(strict_lut, tail_lut))
     return out_bits[:words], out_n[: n.numel()]
 
 

@@ -9,14 +9,17 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import CNT_STRICT_LUT, check, lib
-from .n_to_bits import _dev_guard, _enqueue, _out_bytes, _out_words, _p, _u8, _u64
+from ._lib import check, lib
+from .n_to_bits import _dev_guard, _enqueue, _out_bytes, _out_words, _p, _u8, _u64, encode_flags
 
 
-def n_to_bits2_hip(n):
+def n_to_bits2_hip(n, strict_lut=False, tail_lut=False):
+    """default: the low-3-bit table of n_to_bits2_pext (n_to_bits2.rs:127-136) on every byte;
+    tail_lut=True: n_to_bits2_pext to the letter -- that table up to word (len-5)/27, BYTE_LUT from
+    there on (n_to_bits2.rs:120,179-185); strict_lut=True: n_to_bits2_lut (BYTE_LUT everywhere)."""
     n = _u8(n)
     out = np.empty(lib().cnt_words2_for(n.size), dtype=np.uint64)
-    check(lib().cnt_n_to_bits2(_p(n), n.size, _p(out), out.size))
+    check(lib().cnt_n_to_bits2_ex(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut)))
     return out
 
 
@@ -29,11 +32,11 @@ def bits_to_n2_hip(bits, length):
     return out
 
 
-def n_to_bits2_hip_sharded(n, ndev=0):
+def n_to_bits2_hip_sharded(n, ndev=0, strict_lut=False, tail_lut=False):
     """n_to_bits2_hip with the buffer cut into contiguous chunks over `ndev` GPUs (0 = all)."""
     n = _u8(n)
     out = np.empty(lib().cnt_words2_for(n.size), dtype=np.uint64)
-    check(lib().cnt_n_to_bits2_sharded(_p(n), n.size, _p(out), out.size, ndev))
+    check(lib().cnt_n_to_bits2_sharded_ex(_p(n), n.size, _p(out), out.size, ndev, encode_flags(strict_lut, tail_lut)))
     return out
 
 
@@ -50,14 +53,14 @@ def words2_for(n_len):
     return lib().cnt_words2_for(n_len)
 
 
-def n_to_bits2_dev(n, out=None, strict_lut=False):
+def n_to_bits2_dev(n, out=None, strict_lut=False, tail_lut=False):
     torch = _dev_guard(n)
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     words = lib().cnt_words2_for(n.numel())
     out = _out_words(torch, out, words, n)
     _enqueue(n, lib().cnt_n_to_bits2_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
-             out.numel(), CNT_STRICT_LUT if strict_lut else 0)
+             out.numel(), encode_flags(strict_lut, tail_lut))
     return out[:words]
 
 

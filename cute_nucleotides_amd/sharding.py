@@ -55,6 +55,41 @@ def worker_info(k):
     return dict(zip(("device", "numa_node", "n_cpus", "copy_threads"), (x.value for x in v)))
 
 
+def alias_devices(on):
+    """TEST SUPPORT (cnt_test_alias_devices): let the sharded tiers fold ndev > visible devices onto the devices that
+    exist (shard k -> device k % count).  Returns the previous setting.  Off by default; there is no environment
+    variable for it."""
+    from ._lib import lib
+
+    return bool(lib().cnt_test_alias_devices(1 if on else 0))
+
+
+def _check_placement(shards, outs, extra=None):
+    """The C side runs shard k on device k % visible unconditionally (under alias_devices; device k otherwise): a
+    tensor living anywhere else would reach the kernel as a foreign-device pointer and fault the process.  Lists of
+    unequal length would make the library read past the ctypes arrays.  Both are ValueErrors here."""
+    import ctypes
+
+    import torch
+
+    from ._lib import check, lib
+
+    if len(outs) != len(shards) or (extra is not None and len(extra) != len(shards)):
+        raise ValueError("shards, outs and lengths must have one entry per shard (%d, %d%s)"
+                         % (len(shards), len(outs), "" if extra is None else ", %d" % len(extra)))
+    count = ctypes.c_int(0)
+    check(lib().cnt_device_count(ctypes.byref(count)))
+    if count.value <= 0:
+        raise ValueError("no HIP device visible")
+    aliased = len(shards) > count.value  # only legal under alias_devices(True); the library says CNT_ENODEV otherwise
+    for k, (t, o) in enumerate(zip(shards, outs)):
+        want = k % count.value
+        for x in (t, o):
+            if x.device.index != want:
+                raise ValueError("shard %d lives on %s but the library runs shard k on device k%s = cuda:%d"
+                                 % (k, x.device, " %% %d" % count.value if aliased else "", want))
+
+
 def _ptr_array(values):
     import ctypes
 
@@ -67,15 +102,16 @@ def _size_array(values):
     return (ctypes.c_size_t * len(values))(*values)
 
 
-def n_to_bits_sharded_dev(shards, outs=None, five_letter=False, strict_lut=False, want_ms=False):
+def n_to_bits_sharded_dev(shards, outs=None, five_letter=False, strict_lut=False, want_ms=False, tail_lut=False):
     """Device-resident sharded encode (cnt_n_to_bits[2]_sharded_dev): `shards[k]` is a uint8 CUDA
-    tensor on device k (any device under CNT_SHARD_ALIAS_DEVICES=1); returns the list of int64
+    tensor on device k (device k % visible under alias_devices(True)); returns the list of int64
     word tensors (and the per-shard device milliseconds when want_ms).  Synchronous."""
     import ctypes
 
     import torch
 
-    from ._lib import CNT_STRICT_LUT, check, lib
+    from ._lib import check, lib
+    from .n_to_bits import encode_flags
 
     L = lib()
     words_for = L.cnt_words2_for if five_letter else L.cnt_words_for
@@ -85,16 +121,19 @@ def n_to_bits_sharded_dev(shards, outs=None, five_letter=False, strict_lut=False
             raise ValueError("shards must be contiguous uint8 CUDA tensors")
     if outs is None:
         outs = [torch.empty(w, dtype=torch.int64, device=t.device) for w, t in zip(words, shards)]
+    if len(outs) != len(shards):
+        raise ValueError("outs must have one entry per shard")
     for o, w, t in zip(outs, words, shards):
         if o.dtype != torch.int64 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < w:
             raise ValueError("outs[k] must be a contiguous int64 CUDA tensor on shard k's device with >= words elements")
+    _check_placement(shards, outs)
     for t in shards:  # the library enqueues on its own streams: everything queued on torch's must be done
         torch.cuda.synchronize(t.device)
     ms = (ctypes.c_float * len(shards))() if want_ms else None
     fn = L.cnt_n_to_bits2_sharded_dev if five_letter else L.cnt_n_to_bits_sharded_dev
     check(fn(_ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
              _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), _size_array([o.numel() for o in outs]),
-             len(shards), CNT_STRICT_LUT if strict_lut else 0, ms))
+             len(shards), encode_flags(strict_lut, tail_lut), ms))
     outs = [o[:w] for o, w in zip(outs, words)]
     return (outs, list(ms)) if want_ms else outs
 
@@ -110,6 +149,8 @@ def bits_to_n_sharded_dev(shards, lengths, outs=None, five_letter=False, want_ms
 
     L = lib()
     unit = 27 if five_letter else 32
+    if len(lengths) != len(shards) or (outs is not None and len(outs) != len(shards)):
+        raise ValueError("shards, lengths and outs must have one entry per shard")
     for t, n in zip(shards, lengths):
         if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
             raise ValueError("shards must be contiguous int64 CUDA tensors")
@@ -120,6 +161,7 @@ def bits_to_n_sharded_dev(shards, lengths, outs=None, five_letter=False, want_ms
     for o, n, t in zip(outs, lengths, shards):
         if o.dtype != torch.uint8 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < n:
             raise ValueError("outs[k] must be a contiguous uint8 CUDA tensor on shard k's device with >= length elements")
+    _check_placement(shards, outs, lengths)
     for t in shards:
         torch.cuda.synchronize(t.device)
     ms = (ctypes.c_float * len(shards))() if want_ms else None

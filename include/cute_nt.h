@@ -61,6 +61,16 @@ extern "C" {
  *                     ALL inputs.
  * Both are bit-exact to n_to_bits_lut on the valid alphabet. */
 #define CNT_STRICT_LUT 0x1u
+/*   CNT_TAIL_LUT      the reference's SIMD encoders EXACTLY, on any bytes at any length: bit
+ *                     extraction on whole blocks and BYTE_LUT on the ragged end -- 2-bit codec:
+ *                     the final partial word (`if n.len() & 31 > 0`, n_to_bits.rs:109-111,
+ *                     160-162,201-203,253-255), so default|CNT_TAIL_LUT == n_to_bits_{pext,shift,
+ *                     movemask,mul}; 5-letter codec: every word from (len-5)/27 on (n_to_bits2_pext
+ *                     stops its 32-byte loads there, n_to_bits2.rs:120,179-185).  A property of
+ *                     the WHOLE buffer: the chunked host tier and the sharded host tier apply it
+ *                     to the global end only; the *_sharded_dev entry points treat every shard as
+ *                     a sequence of its own.  No effect together with CNT_STRICT_LUT. */
+#define CNT_TAIL_LUT 0x4u
 
 const char *cnt_strerror(int status);
 int cnt_abi_version(void);
@@ -91,8 +101,9 @@ int cnt_n_to_bits_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_w
 /* Replaces bits_to_n_{lut,shuffle,pdep,clmul}(bits, len) (n_to_bits.rs:51,265,
  * 309,346).  Writes exactly `len` bytes to `out` (the Vec's length). */
 int cnt_bits_to_n(const uint64_t *bits, size_t words, size_t len, uint8_t *out);
-/* Replaces n_to_bits2_{lut,pext}(n) (n_to_bits2.rs:37,118). */
+/* Replaces n_to_bits2_{lut,pext}(n) (n_to_bits2.rs:37,118); _ex takes the encode flags above. */
 int cnt_n_to_bits2(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words);
+int cnt_n_to_bits2_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, unsigned flags);
 /* Replaces bits_to_n2_{lut,pdep}(bits, len) (n_to_bits2.rs:78,196). */
 int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out);
 
@@ -104,13 +115,14 @@ int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out)
  * Each worker (and the copy threads it owns) is pinned to the CPUs of its GPU's
  * NUMA node; CNT_SHARD_NUMA=0 disables that, CNT_SHARD_COPY_THREADS_TOTAL
  * (default 32) bounds the staging-copy threads summed over all devices.
- * ndev > visible devices is CNT_ENODEV -- except under the TEST-ONLY hook
- * CNT_SHARD_ALIAS_DEVICES=1 (shard k runs on device k % count, ndev <= 64), which
- * exists so that the ndev > 1 arithmetic can be exercised on a 1-GPU box. */
+ * ndev > visible devices is CNT_ENODEV (but see cnt_test_alias_devices at the end of
+ * this header).  The _ex forms take the encode flags. */
 int cnt_n_to_bits_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
+int cnt_n_to_bits_sharded_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev, unsigned flags);
 int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
 /* the 5-letter codec over ndev GPUs (shards are whole 128-word tiles = 3456 nt) */
 int cnt_n_to_bits2_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
+int cnt_n_to_bits2_sharded_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev, unsigned flags);
 int cnt_bits_to_n2_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
 /* The partition itself (pure arithmetic, no device needed): shard k of ndev owns
  * nucleotides [*lo, *hi) of n_len; nt_per_word = 32 (2-bit codec: chunk = ceil(n/ndev)
@@ -126,7 +138,7 @@ int cnt_shard_worker_info(int k, int *device, int *numa_node, int *n_cpus, int *
 
 /* ---- multi-GPU device tier: shards already resident, one per device ---------------- */
 /* Arrays of ndev entries; shard k is device memory ON DEVICE k (ndev <= 0: all visible
- * devices; with the test hook above: device k % count).  The calling thread enqueues every
+ * devices; under cnt_test_alias_devices: device k % count).  The calling thread enqueues every
  * shard on a library-owned stream of its device -- the devices then run concurrently -- and
  * returns when all have finished: no host staging, no collective, no helper threads.  The streams
  * are the library's own (non-blocking), so whatever produced the shards must be COMPLETE before the
@@ -227,6 +239,34 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
 int cnt_set_tuning(const char *key, int value);
 int cnt_get_tuning(const char *key, int *value);
 const char *cnt_tuning_name(const char *key, int value);
+
+/* What the launch geometry was sized from, asked of the device (hipDeviceGetAttribute) and cached per
+ * device: compute units, LDS bytes per CU, XCD count (an MI355X in SPX mode: 256 / 163840 / 8; the
+ * partitioned modes and other CDNA parts answer differently, and the residency caps, the persistent
+ * reductions' grids and the XCD-aware tile maps follow).  Any pointer may be NULL. */
+int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xcds);
+
+/* ---- environment variables the host tiers read (all optional) -------------------
+ *   CNT_HOST_COPY_THREADS        staging-copy threads per calling thread (default 4, 1 = none)
+ *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
+ *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
+ *                                pinned completion word (the spin occupies the calling CPU for that long)
+ *   CNT_HOST_HUGEPAGE=0          do NOT madvise(MADV_HUGEPAGE) the 2-MiB-aligned interior of outputs >= 8 MiB.
+ *                                The default advises: a fresh Vec's pages are then faulted in 2-MiB units (a 1-GiB
+ *                                decode 194 -> 72-91 ms); the advice changes the caller's VMA flags for good
+ *                                (possible VMA split, huge-page RSS) -- set 0 if that is not wanted
+ *   CNT_HOST_PREFAULT=0          do NOT fault the pages of large outputs in ahead of the copy-out (helper threads,
+ *                                MADV_POPULATE_WRITE with a touch fallback); CNT_HOST_PREFAULT_THREADS (default 8)
+ *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
+ *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy threads summed over all devices (default 32) */
+
+/* ---- test support ------------------------------------------------------------------
+ * cnt_test_alias_devices(1) lets the sharded tiers accept ndev > visible devices (<= 64) and run
+ * shard k on device k % count, so that the ndev > 1 arithmetic (partition, empty and ragged shards,
+ * per-shard streams) can be exercised on a 1-GPU box.  OFF by default and reachable only through this
+ * call -- no environment variable can make a production process shard onto the wrong device.
+ * Returns the previous setting. */
+int cnt_test_alias_devices(int on);
 
 #ifdef __cplusplus
 }

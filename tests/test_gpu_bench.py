@@ -44,11 +44,22 @@ def test_single_gpu_line_small():
     assert abs(ev["of_spec_8000"] - j["roofline"]["frac"]) < 1e-3 and 0.5 < ev["of_read4_write1_ceiling"] < 1.3
     assert abs(ev["read_only_view_of_spec_8000"] - j["roofline"]["read_only_view"]["frac"]) < 1e-3
     # the 1 GiB configs, measured on the same buffers; the fused pass verified against the two-pass outputs
-    assert j["configs"]["configs[1] n_to_bits encode, 1 GiB (2^30 nt)"]["frac"] > 0.3
+    c1 = j["configs"]["configs[1] n_to_bits encode, 1 GiB (2^30 nt)"]
+    assert c1["frac"] > 0.3 and c1["timing"].startswith("10 launches queued") and c1["isolated_single_launch"]["frac"] > 0.3
     assert j["configs"]["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]["round_trip_verified"] is True
     assert j["fused_round_trip"]["ms_stats"]["verified"] is True
     rag = j["configs"]["ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)"]
     assert rag["round_trip_verified"] is True and rag["encode_frac"] > 0.3 and rag["decode_frac"] > 0.3
+    # the ragged size is ONE launch per call now: within a few percent of the aligned size in the same run
+    assert rag["launches_per_call"] == 1 and 0.9 < rag["encode_vs_aligned_2p30"] < 1.05 and 0.9 < rag["decode_vs_aligned_2p30"] < 1.05
+    # SURVEY 8 f-1 / f-4 on the driver line: 5-letter codec and packed-domain ops at the line's size, verified in-run
+    c5, po = j["codec5"], j["packed_ops"]
+    assert c5["verified"] is True and c5["nt"] == 1 << 30 and abs(c5["algorithmic_bytes_per_nt"] - (1 + 8 / 27)) < 1e-3
+    for d in ("encode", "decode"):
+        assert 0.2 < c5[d]["frac"] < 1.0 and c5[d]["ms"]["n"] == 4 and abs(c5[d]["frac"] - c5[d]["achieved_GBs"] / 8000.0) < 1e-3
+    assert po["verified"] is True and po["parity"].startswith("unpinned")
+    for op, bpn in (("hamming", 0.5), ("complement", 0.5), ("reverse_complement", 0.5), ("validate", 1.0)):
+        assert po[op]["bytes_per_nt"] == bpn and 0.2 < po[op]["frac"] < 1.0, (op, po[op])
     # configs[4]'s per-GPU shard (reduced to 2^31 nt here), and this rank's device identity
     sh = j["configs4_sharded_encode"]
     assert sh["nt_per_gpu"] == 1 << 31 and sh["ranks_measured"] == 1 and sh["per_gpu_gnts"]["min"] > 1000
@@ -89,6 +100,40 @@ def test_two_rank_launch_path_shares_one_gpu():
     assert o["encode_read_view_frac"]["min"] <= o["encode_read_view_frac"]["max"]
     sh = j["configs4_sharded_encode"]
     assert sh["ranks_measured"] == 2 and sh["nt_per_gpu"] == 1 << 29 and sh["total_GiB"] == 1.0 and sh["aggregate_gnts"] > 0
+
+
+def test_gpus_n_without_a_launcher_is_one_process_over_n_devices():
+    """`python bench.py --gpus N` launched plainly used to exit ("needs a torch.distributed.run
+    launch").  It now drives the N devices from ONE process through cnt_n_to_bits_sharded_dev / cnt_bits_to_n_sharded_dev
+    and prints the same JSON line.  On the 1-GPU box the N shards are folded onto cuda:0 (CNT_BENCH_SHARE_GPU=1 ->
+    cnt_test_alias_devices); without that the shortage of devices is a clear error, not a wrong run."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-nt", "28", "--shard-log2-nt", "29"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, CNT_BENCH_SHARE_GPU="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _last_json(out.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified"] is True and j["steps"] == 3
+    assert j["config"]["nt_per_gpu"] == 1 << 28 and j["config"]["nt_per_step"] == 2 * 2 * (1 << 28) and "single process" in j["config"]["launch"]
+    assert j["devices"]["processes"] == 1 and j["devices"]["data_path_collective"] is None and j["devices"]["control_plane"] is None
+    rows = j["ranks"]
+    assert [r["rank"] for r in rows] == [0, 1] and rows[0]["pid"] == rows[1]["pid"]
+    assert rows[0]["first_nt"] == 0 and rows[1]["first_nt"] == 1 << 28 and all(r["nt"] == 1 << 28 for r in rows)
+    for r in rows:
+        assert r["encode_ms"]["n"] == 3 and 0 < r["encode_frac"] < 1 and 0 < r["decode_frac"] < 1 and r["pci_bus_id"]
+        assert r["configs4_shard"]["nt"] == 1 << 29 and r["configs4_shard"]["round_trip_verified"] is True
+    assert rows[1]["configs4_shard"]["first_nt"] == 1 << 29
+    sh = j["configs4_sharded_encode"]
+    assert sh["ranks_measured"] == 2 and sh["nt_per_gpu"] == 1 << 29 and sh["aggregate_gnts"] > 0
+    assert abs(j["value"] - j["config"]["nt_per_step"] * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"]) / 1e9) < 0.01 * j["value"]
+    for key in ("roofline", "roofline_decode"):
+        assert j[key]["bound"] == "hbm" and abs(j[key]["frac"] - j[key]["achieved"] / j[key]["peak"]) < 1e-3
+    # more devices than exist and no test hook: a clear refusal
+    import torch
+
+    too_many = str(torch.cuda.device_count() + 1)
+    env = {k: v for k, v in os.environ.items() if k != "CNT_BENCH_SHARE_GPU"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", too_many, "--steps", "1", "--warmup", "0", "--log2-nt", "24"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "visible" in out.stderr and out.stdout.strip() == ""
 
 
 def test_criterion_twin_runs_and_self_checks():
@@ -156,6 +201,11 @@ def test_cpu_baseline_and_host_tier_blocks():
     x = h["crossover_vs_one_cpu_thread"]["n_to_bits_hip vs n_to_bits_movemask"]
     assert x["host_tier_ahead_from"] is None or x["host_tier_ahead_from"] in x["table_GiBs"]
     assert len(x["table_GiBs"]) == 10
+    # same-run PCIe ceilings (pinned hipMemcpy) and the host tier's fraction of them at 1 GiB, reused and fresh outputs
+    assert 10.0 < h["pcie_ceiling"]["h2d_GiBs"] < 70.0 and 10.0 < h["pcie_ceiling"]["d2h_GiBs"] < 70.0
+    fr = h["frac_of_pcie_ceiling_at_2^30"]
+    assert len(fr) == 4 and all(0.02 < v < 1.2 for v in fr.values()), fr
+    assert set(h["fresh_over_reused_at_2^30"]) == {"n_to_bits_hip", "bits_to_n_hip"}
     # roofline.traffic: HBM bytes per launch measured by THIS run (two rocprofv3 --pmc child passes, calibrated on
     # known-size probes) -- equal to the algorithmic bytes to well under 1 %: nothing is re-read
     for key in ("roofline", "roofline_decode"):

@@ -15,7 +15,7 @@ VALID = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
 SIZES = [1, 3, 4, 31, 32, 33, 63, 64, 65, 255, 256, 4095, 4096, 4097, 16383, 16384, 16385,
          32768 + 5, 65536, 100003, (1 << 20), (1 << 20) + 13, (1 << 22) + 16384 + 31]
 
-N_ENC_VARIANTS, N_DEC_VARIANTS = 14, 18  # kEncodeVariants / kDecodeVariants in csrc/codec2_launch.hpp (checked below)
+N_ENC_VARIANTS, N_DEC_VARIANTS = 17, 27  # kEncodeVariants / kDecodeVariants in csrc/codec2_launch.hpp (checked below)
 
 
 @pytest.fixture(scope="module")
@@ -678,3 +678,161 @@ def test_small_call_path_is_thread_safe(cn, oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not bad, bad[:5]
+
+
+# ---- CNT_TAIL_LUT: the reference's SIMD encoders to the letter, on ARBITRARY bytes ---------------------------------
+TAIL_SIZES = [1, 5, 31, 32, 33, 63, 65, 100, 2048 + 17, 4096 + 31, 40000 + 13, 100003, (1 << 20) + 7, (1 << 20) + 32, (1 << 22) + 16384 + 29]
+
+
+def test_tail_lut_equals_the_simd_variants_on_arbitrary_bytes(cn, oracle, torch_cuda, tuning):
+    """n_to_bits_{pext,shift,movemask,mul} extract bits 1..2 on whole 32-nt blocks and send the ragged end through
+    BYTE_LUT (n_to_bits.rs:109-111,160-162,201-203,253-255): on bytes outside the alphabet neither the default mode
+    ((b>>1)&3 everywhere) nor CNT_STRICT_LUT (table everywhere) equals them -- default | CNT_TAIL_LUT does, at any
+    length, through the host tier, the device tier (tiles + edge workgroups, generic kernel) and the sharded tiers."""
+    from cute_nucleotides_amd import sharding
+
+    if not oracle.port_cpu_ok():
+        pytest.skip("host CPU lacks AVX2/BMI2: the SIMD ports cannot run")
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    prev = sharding.alias_devices(True)
+    try:
+        for n_len in TAIL_SIZES:
+            n = rng.integers(0, 128, n_len, dtype=np.uint8)  # any 7-bit byte: 88 of the 128 differ between table and bit extraction
+            want = oracle.n_to_bits_movemask(n)
+            for port in (oracle.n_to_bits_pext, oracle.n_to_bits_shift, oracle.n_to_bits_mul):
+                assert np.array_equal(port(n), want), (n_len, port.__name__)  # the four reference variants agree with each other
+            assert np.array_equal(cn.n_to_bits_hip(n, tail_lut=True), want), n_len  # host tier (staged small path / pipeline)
+            d = torch.from_numpy(n).cuda()
+            for small_nt in (0, 1 << 17):  # tiles + edge workgroups, and the generic kernel alone
+                tuning.set_tuning("small_nt", small_nt)
+                got = cn.n_to_bits_dev(d, tail_lut=True).cpu().numpy().view(np.uint64)
+                assert np.array_equal(got, want), (n_len, small_nt)
+            off = torch.zeros(n_len + 64, dtype=torch.uint8, device="cuda")  # the window kernel's launch (input phase != 0)
+            off[13 : 13 + n_len].copy_(d)
+            assert np.array_equal(cn.n_to_bits_dev(off[13 : 13 + n_len], tail_lut=True).cpu().numpy().view(np.uint64), want), n_len
+            f_bits, _ = cn.round_trip_dev(d, tail_lut=True)
+            assert np.array_equal(f_bits.cpu().numpy().view(np.uint64), want), n_len
+            for ndev in (1, 3, 8):
+                assert np.array_equal(cn.n_to_bits_hip_sharded(n, ndev=ndev, tail_lut=True), want), (n_len, ndev)
+            (s_bits,) = sharding.n_to_bits_sharded_dev([d], tail_lut=True)
+            assert np.array_equal(s_bits.cpu().numpy().view(np.uint64), want), n_len
+            assert np.array_equal(want, oracle.n_to_bits_bitextract(n)), n_len  # the oracle's scalar statement of the same rule
+            # without the flag the default stays (b>>1)&3 everywhere; with CNT_STRICT_LUT the table everywhere
+            codes = ((np.concatenate([n, np.zeros(-n_len % 32, dtype=np.uint8)]) >> 1) & 3).astype(np.uint64).reshape(-1, 32)
+            everywhere = (codes << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+            assert np.array_equal(cn.n_to_bits_hip(n), everywhere), n_len
+            assert np.array_equal(cn.n_to_bits_hip(n, strict_lut=True, tail_lut=True), oracle.n_to_bits_lut(n)), n_len
+    finally:
+        sharding.alias_devices(prev)
+
+
+# ---- one launch per call: head and ragged end ride in the tile kernel's grid --------------------------------------
+def _hip_runtime():
+    """the HIP runtime already mapped in this process (torch's), for the three graph calls the test needs"""
+    import ctypes
+
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    assert paths, "no HIP runtime mapped"
+    return ctypes.CDLL(paths[0])
+
+
+def _kernel_nodes_of(torch, fn):
+    """enqueue fn() under stream capture and count the nodes of the captured graph"""
+    import ctypes
+
+    hip = _hip_runtime()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fn()  # module load / lazy init outside the capture
+        side.synchronize()
+        s = ctypes.c_void_p(side.cuda_stream)
+        graph = ctypes.c_void_p()
+        assert hip.hipStreamBeginCapture(s, 2) == 0  # hipStreamCaptureModeRelaxed
+        try:
+            fn()
+        finally:
+            rc = hip.hipStreamEndCapture(s, ctypes.byref(graph))
+        assert rc == 0
+        n = ctypes.c_size_t(0)
+        assert hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) == 0
+        hip.hipGraphDestroy(graph)
+    return n.value
+
+
+def test_any_size_and_alignment_is_one_launch(cn, oracle, torch_cuda, tuning):
+    """VERDICT r02 item 3: encode_dev / decode_dev used to enqueue up to three kernels (head peel, tiles, ragged end);
+    each extra launch cost ~5 us behind a 0.2 ms kernel at BASELINE.json's 1 GiB size.  The head words and the ragged
+    end are now extra workgroups of the tile kernel's own grid: ONE node in a captured graph for every size and
+    pointer phase -- and the results are still the oracle's."""
+    torch = torch_cuda
+    tuning.set_tuning("small_nt", 0)
+    n_len = (1 << 21) - 19
+    host = _rand_valid(n_len, 4)
+    want = oracle.n_to_bits_lut(host)
+    want_back = oracle.bits_to_n_lut(want, n_len)  # the canonical spelling: upper case, U -> T
+    ibuf = torch.zeros(n_len + 256, dtype=torch.uint8, device="cuda")
+    pbuf = torch.zeros(n_len // 32 + 64, dtype=torch.int64, device="cuda")
+    obuf = torch.zeros(n_len + 8192, dtype=torch.uint8, device="cuda")
+    words = (n_len + 31) // 32
+    for io, po, oo in ((0, 0, 0), (0, 3, 0), (5, 0, 77), (64, 1, 4095), (127, 7, 1), (16, 0, 16)):
+        view = ibuf[io : io + n_len]
+        view.copy_(torch.from_numpy(host))
+        packed = pbuf[po : po + words]
+        out = obuf[oo : oo + n_len]
+        assert _kernel_nodes_of(torch, lambda: cn.n_to_bits_dev(view, out=packed)) == 1, (io, po)
+        assert np.array_equal(packed.cpu().numpy().view(np.uint64), want), (io, po)
+        assert _kernel_nodes_of(torch, lambda: cn.bits_to_n_dev(packed, n_len, out=out)) == 1, (po, oo)
+        assert np.array_equal(out.cpu().numpy(), want_back), (po, oo)
+    # shorter than one tile: the generic kernel alone, also one launch
+    small = ibuf[3 : 3 + 1000]
+    assert _kernel_nodes_of(torch, lambda: cn.n_to_bits_dev(small, out=pbuf[:32])) == 1
+
+
+# ---- BASELINE.json configs[4]: every rank's shard of the 256 GiB job, at its GLOBAL offset ---------------------------
+@pytest.mark.parametrize("k", range(8))
+def test_config4_rank_shard_at_its_global_offset(cn, oracle, torch_cuda, fullsize, k):
+    """"256 GiB encode chunk-sharded across 8 x MI355X": rank k's exact workload -- the 2^35-nt chunk
+    [k * 2^35, (k+1) * 2^35) of the global counter-based ACGT stream -- on this GPU: partition from the C library
+    (cnt_shard_range), encode through the device-resident sharded entry point, sampled 16 Mi-nt chunks and the last
+    words against n_to_bits_lut of the oracle REGENERATED AT THE GLOBAL OFFSETS, position-salted checksums at the
+    global word index, and a device round trip.  Word w depends on nt [32w, 32w+32) only (n_to_bits.rs:38-43), so the
+    eight shards' words concatenated ARE the 256 GiB buffer's words."""
+    from cute_nucleotides_amd import devutil, sharding
+
+    torch = torch_cuda
+    world, shard_nt, seed = 8, 1 << 35, 0x5EED + 4
+    n_global = world * shard_nt
+    lo, hi = sharding.shard_range_c(n_global, world, k)
+    assert (lo, hi) == (k * shard_nt, (k + 1) * shard_nt) == sharding.partition(n_global, world)[k]
+    need_free_hbm(76)  # 32 + 8 + 32 GiB resident
+    d = torch.empty(hi - lo, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d, seed, first_nt=lo)
+    packed = torch.empty((hi - lo) // 32, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    (bits,), (ms,) = sharding.n_to_bits_sharded_dev([d], outs=[packed], want_ms=True)
+    fullsize(35, ms, config="configs[4] rank %d of 8" % k, first_nt=lo, gnts=round((hi - lo) / (ms * 1e-3) / 1e9, 1))
+    chunk_nt = 16 << 20
+    chunk_w = chunk_nt // 32
+    n_chunks = (hi - lo) // chunk_nt
+    rng = np.random.default_rng(100 + k)
+    for c in sorted({0, n_chunks - 1, int(rng.integers(1, n_chunks - 1)), int(rng.integers(1, n_chunks - 1))}):
+        host_n = oracle.fill_random_acgt(chunk_nt, seed, first_nt=lo + c * chunk_nt)  # GLOBAL offset
+        assert np.array_equal(d[c * chunk_nt : c * chunk_nt + 4096].cpu().numpy(), host_n[:4096]), (k, c)  # the shard holds the global stream
+        want = oracle.n_to_bits_lut(host_n)
+        got = bits[c * chunk_w : (c + 1) * chunk_w].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), (k, c)
+        first_word = lo // 32 + c * chunk_w  # global word index: the salt of the checksum
+        assert devutil.checksum_words(bits[c * chunk_w : (c + 1) * chunk_w], first_word=first_word) == oracle.checksum_words(want, first_word=first_word), (k, c)
+    back = torch.empty(hi - lo, dtype=torch.uint8, device="cuda")
+    sharding.bits_to_n_sharded_dev([bits], [hi - lo], outs=[back])
+    assert devutil.count_mismatch(d, back) == 0
+    # the ragged end of the job: the last rank's shard minus 19 nt -> 13 nucleotides in the final word, zero-padded
+    if k == world - 1:
+        r = (hi - lo) - 19
+        (rb,) = sharding.n_to_bits_sharded_dev([d[:r]], outs=[packed])
+        tail_n = oracle.fill_random_acgt(chunk_nt, seed, first_nt=hi - chunk_nt)[: chunk_nt - 19]
+        want = oracle.n_to_bits_lut(tail_n)
+        got = rb[-(chunk_w) :].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want) and int(got[-1]) >> 26 == 0

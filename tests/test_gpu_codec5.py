@@ -268,3 +268,43 @@ def test_caller_supplied_outputs_are_validated(cn):
 
     cur = ctypes.c_int(-1)
     assert _lib.lib().cnt_get_device(ctypes.byref(cur)) == 0 and cur.value == 0
+
+
+# ---- CNT_TAIL_LUT: n_to_bits2_pext to the letter, on arbitrary bytes --------------------------------------------------
+TAIL_SIZES5 = [1, 4, 5, 6, 26, 27, 28, 31, 32, 33, 53, 54, 58, 59, 60, 81, 3456, 3456 + 4, 3456 + 5, 3456 * 3, 3456 * 3 + 31, 3456 * 3 + 32,
+               100003, 27 * 40000, 27 * 40000 + 5, (1 << 20) + 11, 27 * (1 << 19) + 13824 * 2, 27 * (1 << 19) + 13824 * 2 + 4]
+
+
+def test_tail_lut_equals_n_to_bits2_pext_on_arbitrary_bytes(cn, oracle):
+    """n_to_bits2_pext runs its low-3-bit table over words [0, (len-5)/27) -- its 32-byte loads would over-read 5 bytes
+    beyond that -- and hands every later word (one or two, whole or ragged) to n_to_bits2_lut (n_to_bits2.rs:120,179-185).
+    On foreign bytes the two tables differ ('B' = 0x42 has low bits 010 -> 0 in both, but 'D' = 0x44 -> T in the fast
+    table, 0 in BYTE_LUT), so neither the default nor CNT_STRICT_LUT alone equals it at every length; default |
+    CNT_TAIL_LUT does: host tier (small path + chunked pipeline), device tier (tiles + generic), sharded tier."""
+    import torch
+
+    from cute_nucleotides_amd import devutil, n_to_bits2 as n2, sharding
+
+    if not oracle.port_cpu_ok():
+        pytest.skip("host CPU lacks AVX2/BMI2: the SIMD port cannot run")
+    rng = np.random.default_rng(77)
+    saved = devutil.get_tuning("small_nt")
+    prev = sharding.alias_devices(True)
+    try:
+        for n_len in TAIL_SIZES5:
+            n = rng.integers(0, 128, n_len, dtype=np.uint8)
+            want = oracle.n_to_bits2_pext(n)
+            assert np.array_equal(n2.n_to_bits2_hip(n, tail_lut=True), want), n_len
+            d = torch.from_numpy(n).cuda()
+            for small_nt in (0, 1 << 17):
+                devutil.set_tuning("small_nt", small_nt)
+                assert np.array_equal(n2.n_to_bits2_dev(d, tail_lut=True).cpu().numpy().view(np.uint64), want), (n_len, small_nt)
+            off = torch.zeros(n_len + 64, dtype=torch.uint8, device="cuda")  # input phase != 0: the window kernel's launch
+            off[5 : 5 + n_len].copy_(d)
+            assert np.array_equal(n2.n_to_bits2_dev(off[5 : 5 + n_len], tail_lut=True).cpu().numpy().view(np.uint64), want), n_len
+            for ndev in (1, 3, 8):
+                assert np.array_equal(n2.n_to_bits2_hip_sharded(n, ndev=ndev, tail_lut=True), want), (n_len, ndev)
+            assert np.array_equal(n2.n_to_bits2_hip(n, strict_lut=True, tail_lut=True), oracle.n_to_bits2_lut(n)), n_len
+    finally:
+        devutil.set_tuning("small_nt", saved)
+        sharding.alias_devices(prev)

@@ -99,8 +99,18 @@ def test_five_letter_codec_fuzz(oracle, small_nt, seed):
         assert (d[:off_d] == 0x5A).all() and (d[off_d + length :] == 0x5A).all()
 
 
+@pytest.fixture()
+def alias():
+    """cnt_test_alias_devices(1) for one test: shard k -> device k % count on the 1-GPU box"""
+    from cute_nucleotides_amd import sharding
+
+    prev = sharding.alias_devices(True)
+    yield
+    sharding.alias_devices(prev)
+
+
 @pytest.mark.parametrize("seed", range(3 * SEEDS))
-def test_host_and_sharded_tiers_fuzz(oracle, seed, monkeypatch):
+def test_host_and_sharded_tiers_fuzz(oracle, seed, alias):
     """host-slice entry points: the zero-copy small path (staged kernels + completion flag), the 2-slot pipeline, and
     the sharded tier with a random number of aliased shards -- random lengths around every path's limits, both codecs,
     arbitrary bytes for the 2-bit encoder in both modes"""
@@ -109,7 +119,6 @@ def test_host_and_sharded_tiers_fuzz(oracle, seed, monkeypatch):
     import cute_nucleotides_amd as cn
     from cute_nucleotides_amd import _lib, n_to_bits2 as n2
 
-    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")
     L = _lib.lib()
     rng = np.random.default_rng(500 + seed)
     alpha = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)

@@ -1,6 +1,6 @@
 """The sharded tier with ndev > 1 (BASELINE.json configs[4]: "chunk-sharded across 8 x MI355X ... no
 collective; per-GPU outputs concatenated on the host").  The GPU box has ONE device, so these tests
-set the library's test-only hook CNT_SHARD_ALIAS_DEVICES=1 (shard k -> device k % count): the
+switch on the library's test support cnt_test_alias_devices(1) (shard k -> device k % count): the
 partition arithmetic of cnt_*_sharded, the multi-worker pool, the empty-shard path, the ragged
 last shard and the per-shard output offsets all run exactly as they would on an 8-GPU node -- only the
 device binding is folded onto cuda:0.  Everything is compared with the CPU oracle bit for bit, with
@@ -24,8 +24,11 @@ def L():
 
 
 @pytest.fixture()
-def alias(monkeypatch):
-    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")  # os.environ -> putenv: the C getenv sees it
+def alias(L):
+    """cnt_test_alias_devices(1) for the duration of one test (an explicit call: no environment variable exists)"""
+    prev = L.cnt_test_alias_devices(1)
+    yield
+    L.cnt_test_alias_devices(prev)
 
 
 def _p(a, off_bytes=0):
@@ -110,11 +113,15 @@ def test_alias_hook_is_opt_in_and_bounded(L, oracle, monkeypatch):
     count = torch.cuda.device_count()
     n = oracle.fill_random_acgt(40000, 3)
     out = np.zeros(1250, dtype=np.uint64)
-    monkeypatch.delenv("CNT_SHARD_ALIAS_DEVICES", raising=False)
+    assert L.cnt_test_alias_devices(0) == 0  # off by default
+    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")  # round 2's environment hook is gone: a variable changes nothing
     assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, count + 1) == _lib.CNT_ENODEV  # production behaviour
-    monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")
-    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 65) == _lib.CNT_ENODEV  # the hook stops at 64 shards
-    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 64) == 0
+    assert L.cnt_test_alias_devices(1) == 0
+    try:
+        assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 65) == _lib.CNT_ENODEV  # the hook stops at 64 shards
+        assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 64) == 0
+    finally:
+        assert L.cnt_test_alias_devices(0) == 1
     assert np.array_equal(out, oracle.n_to_bits_lut(n))
     # argument errors come before any device work, as for the unsharded calls
     assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), 1249, 4) == _lib.CNT_ECAP
@@ -190,7 +197,7 @@ def test_device_resident_shards_match_the_oracle(L, oracle, alias, monkeypatch, 
     from cute_nucleotides_amd import sharding
 
     if ndev == 1:
-        monkeypatch.delenv("CNT_SHARD_ALIAS_DEVICES")  # the production path: one real device, no hook
+        L.cnt_test_alias_devices(0)  # the production path: one real device, no hook
     sizes = [(1 << 21) + 13, 0, 40000, 2048 * 5, 77, (1 << 20), 16384 * 3 + 1, 1][:ndev]
     for five in (False, True):
         gen = oracle.fill_random_acgtn if five else oracle.fill_random_acgt
@@ -274,9 +281,9 @@ def test_single_process_sharded_bench_script(alias):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CNT_SHARD_ALIAS_DEVICES="1")
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, os.path.join(root, "bench", "bench_sharded_dev.py"), "--ndev", "4", "--log2-nt", "28", "--iters", "3",
-                          "--decode"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+                          "--decode", "--alias"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["ndev"] == 4 and j["alias_test_hook"] is True and j["verified"] is True and j["data_path_collective"] is None

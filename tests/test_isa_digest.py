@@ -1,0 +1,91 @@
+"""Instruction selection of the shipped kernels, pinned on the CPU box: DESIGN.md argues from the
+disassembly -- streaming `nt` loads, write-through `sc0 sc1 nt` stores, `v_perm_b32` letter tables, `v_dot4_u32_u8`
+in the 5-letter packer, no waterfall loops, no scratch, register counts far below the residency caps -- and nothing
+checked it: a compiler bump could reintroduce a waterfall loop and only show up as a few percent on the GPU box.
+hipcc cross-compiles gfx950 without a GPU, so the assembly of the library's one translation unit is regenerated here
+(~5 s), compared with the committed digest (profiles/r03_isa_digest.txt) and checked property by property."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bench"))
+
+
+@pytest.fixture(scope="module")
+def isa():
+    import isa_digest
+
+    found = isa_digest.kernels(isa_digest.assembly())
+    return isa_digest, found
+
+
+def _tile(isa_digest, found, name):
+    assert name in found, "kernel not in the code object: " + name
+    return isa_digest.summarise(found[name], True), isa_digest.summarise(found[name], False), found[name]["meta"]
+
+
+def test_committed_digest_is_current(isa):
+    isa_digest, found = isa
+    want = open(isa_digest.DIGEST).read()
+    got = isa_digest.digest(found)
+    assert "MISSING" not in got
+    assert got == want, "the compiler's output changed: review the diff, then `python bench/isa_digest.py --write`"
+
+
+def test_every_shipped_kernel_is_lean(isa):
+    isa_digest, found = isa
+    for label, name in isa_digest.SHIPPED:
+        t, w, m = _tile(isa_digest, found, name)
+        assert m["private_segment_fixed_size"] == 0 and "scratch_" not in w["counts"], (label, "scratch")
+        # the residency caps are set with dummy LDS (<= 6 waves per SIMD): anything under 85 VGPRs changes nothing
+        assert m["next_free_vgpr"] <= 84, (label, m)
+        # a waterfall loop (non-uniform buffer descriptor) is `s_xor_b64 exec, exec` + `s_cbranch_execnz` around the access
+        assert "s_xor_b64 exec, exec" not in w["counts"], (label, "waterfall loop")
+        assert "global_load" not in t["counts"] and "global_store" not in t["counts"], (label, "tile accesses go through raw buffer ops")
+
+
+def test_2bit_codec_instruction_selection(isa):
+    isa_digest, found = isa
+    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_stream<64, 2, 2, 2, 19, false>")
+    assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
+    assert t["counts"]["buffer_load_dwordx4"] == 2 and t["counts"]["buffer_store_dword"] == 2
+    assert "s_and_saveexec_b64" not in t["counts"] and "v_readfirstlane_b32" not in t["counts"]  # nothing divergent in front of the stores
+    assert t["counts"]["v_mul_lo_u32"] == 8  # y*0x41041: the reference's n_to_bits_mul identity, found by the compiler
+    assert m["group_segment_fixed_size"] == 0 and t["instructions"] <= 90
+    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_window<2, 2, 19, false>")
+    assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["v_alignbit_b32"] == 2
+    assert t["counts"]["buffer_load_dwordx4"] == 3 and "s_and_saveexec_b64" not in t["counts"]
+    for name in ("void cnt::bits_to_n_stream<128, 2, 4, 0, 19>", "void cnt::bits_to_n_shifted<128, 2, 4, 0, 19>"):
+        t, w, m = _tile(isa_digest, found, name)
+        assert t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["buffer_store_dwordx4"] == 2
+        assert t["counts"]["v_perm_b32"] == 8  # the 4-entry "ACTG" table, one per packed byte
+        assert "s_and_saveexec_b64" not in t["counts"] and m["next_free_vgpr"] <= 24
+    t, w, m = _tile(isa_digest, found, "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>")
+    assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
+    assert t["counts"]["buffer_load_dwordx4"] == 4 and t["counts"]["buffer_store_dword"] == 4 and t["counts"]["buffer_store_dwordx4"] == 4
+    assert "s_and_saveexec_b64" not in w["counts"]
+
+
+def test_5letter_codec_instruction_selection(isa):
+    isa_digest, found = isa
+    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits2_wave<1, 2, 2, 16, false, 1>")
+    assert t["counts"]["v_dot4_u32_u8"] == 26  # 13 byte dot products per word, two words per lane
+    assert t["counts"]["v_perm_b32"] >= 14 and t["load_policies"] == ["nt"] and t["counts"]["buffer_store_dwordx2"] == 2
+    assert 3400 <= m["group_segment_fixed_size"] <= 3584  # the wave's slab; the launcher's cap arithmetic assumes <= 3584
+    t, w, m = _tile(isa_digest, found, "void cnt::bits_to_n2_wave<1, 2, 0, 19, 4>")
+    assert t["counts"]["v_pk_"] >= 40 and t["counts"]["v_perm_b32"] >= 40  # packed 16-bit /25, /5 and the weave
+    assert t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["buffer_store_dwordx4"] == 4
+    assert 3400 <= m["group_segment_fixed_size"] <= 3584
+
+
+def test_packed_ops_instruction_selection(isa):
+    isa_digest, found = isa
+    for name, loads in (("void cnt::hamming_persist<8>", 32), ("void cnt::validate_persist<16, false>", 32)):
+        t, w, m = _tile(isa_digest, found, name)
+        assert w["counts"]["buffer_load_dwordx4"] == loads and w["load_policies"] == ["nt"]  # prologue + steady-state loads of the software pipeline
+        assert "buffer_store_dword" not in w["counts"] and m["next_free_vgpr"] >= 64  # the pipeline lives in registers: 16 vectors in flight
+    for name in ("void cnt::complement_tiles<256, 1>", "void cnt::reverse_complement_tiles<256>"):
+        t, w, m = _tile(isa_digest, found, name)
+        assert t["store_policies"] == ["sc0 nt sc1"] and t["load_policies"] == ["nt"]
