@@ -442,6 +442,18 @@ def measure_host_tier(seed):
             out = np.empty(m, dtype=np.uint8)
             return L.cnt_bits_to_n(p(bits), words, m, p(out))
 
+        kept = []  # "dropped later": the result outlives the call and is freed outside the timed loop (criterion's iter_with_large_drop)
+
+        def enc_fresh_kept():
+            out = np.empty(words, dtype=np.uint64)
+            kept.append(out)
+            return L.cnt_n_to_bits(p(n), m, p(out), words)
+
+        def dec_fresh_kept():
+            out = np.empty(m, dtype=np.uint8)
+            kept.append(out)
+            return L.cnt_bits_to_n(p(bits), words, m, p(out))
+
         def enc_reuse():
             return L.cnt_n_to_bits(p(n), m, p(bits), words)
 
@@ -461,6 +473,17 @@ def measure_host_tier(seed):
                     break
             row[name] = round(m / (dt / k) / 2**30, 3)
             row[name + " us"] = round(dt / k * 1e6, 2)
+        if log2 >= 26:  # large outputs: the same fresh-output calls with the DROP of the result outside the timed loop
+            for name, fn in (("n_to_bits_hip fresh out, dropped later", enc_fresh_kept), ("bits_to_n_hip fresh out, dropped later", dec_fresh_kept)):
+                reps = 3 if log2 >= 30 else 6
+                fn()
+                kept.clear()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                dt = time.perf_counter() - t0
+                kept.clear()
+                row[name + " us"] = round(dt / reps * 1e6, 2)
         assert np.array_equal(back, n)
         rows["2^%d" % log2] = row
     return rows
@@ -1164,8 +1187,13 @@ def main():
                     "pcie_ceiling": dict(pcie, what="pinned hipMemcpy of 1 GiB, median of 5, same run"),
                     "frac_of_pcie_ceiling_at_2^%d" % HOST_TIER_LOG2[-1]: frac,
                     "fresh_over_reused_at_2^%d" % HOST_TIER_LOG2[-1]: {
-                        "n_to_bits_hip": round(big["n_to_bits_hip fresh out us"] / big["n_to_bits_hip reused out us"], 3),
-                        "bits_to_n_hip": round(big["bits_to_n_hip fresh out us"] / big["bits_to_n_hip reused out us"], 3)},
+                        "what": "time of a call whose output is allocated inside it over the time into a reused output; `drop_inside` also frees the "
+                                "PREVIOUS result inside the timed loop (what criterion's iter does; on this host munmap costs ~47 ms per GiB of huge pages, "
+                                "120 ms per GiB of 4-KiB pages, with or without HIP in the process: bench/munmap_lab.cpp), `drop_outside` frees it later",
+                        "n_to_bits_hip": {"drop_inside": round(big["n_to_bits_hip fresh out us"] / big["n_to_bits_hip reused out us"], 3),
+                                          "drop_outside": round(big["n_to_bits_hip fresh out, dropped later us"] / big["n_to_bits_hip reused out us"], 3)},
+                        "bits_to_n_hip": {"drop_inside": round(big["bits_to_n_hip fresh out us"] / big["bits_to_n_hip reused out us"], 3),
+                                          "drop_outside": round(big["bits_to_n_hip fresh out, dropped later us"] / big["bits_to_n_hip reused out us"], 3)}},
                     "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread; "
                             "`fresh out` allocates the output inside the timed call like the reference's functions do; microseconds per call "
                             "at 2^k nt (GiB/s of the fresh-out calls are in the crossover table)",

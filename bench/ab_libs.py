@@ -30,6 +30,7 @@ ap.add_argument("--rounds", type=int, default=10)
 ap.add_argument("--decode-variants", default="", help="comma list: extra rows of the first library with cnt_set_tuning('decode', v)")
 ap.add_argument("--encode-variants", default="")
 ap.add_argument("--probes", action="store_true", help="also time bench/libcnt_probes.so's 4:1 and 1:4 no-arithmetic streams")
+ap.add_argument("--arith", action="store_true", help="with --probes: the 4:1 / 1:4 streams with the codec's arithmetic applied 1, 2, 4, 8 times")
 ap.add_argument("--queue", type=int, default=1, help="launches per event pair (1 = isolated launches)")
 a = ap.parse_args()
 
@@ -78,6 +79,10 @@ if a.probes and a.minus == 0:
     P.probe_shipped.argtypes = [ctypes.c_int, _vp, _vp, _sz, _vp]
     rows.append(("probe 4:1", "encode", lambda: P.probe_shipped(2, d_in.data_ptr(), d_out.data_ptr(), n_len, stream)))
     rows.append(("probe 1:4", "decode", lambda: P.probe_shipped(3, d_in.data_ptr(), d_out.data_ptr(), n_len, stream)))
+    if a.arith:  # the same streams with the codec's arithmetic applied R times in a dependent chain
+        for r in (1, 2, 4, 8):
+            rows.append(("probe 4:1 arith x%d" % r, "encode", lambda r=r: P.probe_shipped(20 + r, d_in.data_ptr(), d_out.data_ptr(), n_len, stream)))
+            rows.append(("probe 1:4 arith x%d" % r, "decode", lambda r=r: P.probe_shipped(10 + r, d_in.data_ptr(), d_out.data_ptr(), n_len, stream)))
 
 for _, _, fn in rows:  # warm-up: module load, stream creation
     assert fn() == 0

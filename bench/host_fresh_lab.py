@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SETTINGS = [
-    ("default (hugepage advice + prefault team of 8)", {}),
+    ("default (hugepage advice + prefault team, 3 pipeline slots)", {}),
     ("CNT_HOST_PREFAULT=0 (round 2: hugepage advice only)", {"CNT_HOST_PREFAULT": "0"}),
     ("prefault team of 4", {"CNT_HOST_PREFAULT_THREADS": "4"}),
     ("prefault team of 16", {"CNT_HOST_PREFAULT_THREADS": "16"}),
@@ -28,6 +28,11 @@ SETTINGS = [
     ("no prefault, 8 copy threads", {"CNT_HOST_PREFAULT": "0", "CNT_HOST_COPY_THREADS": "8"}),
     ("prefault team of 8, no hugepage advice", {"CNT_HOST_HUGEPAGE": "0"}),
     ("neither (round 1)", {"CNT_HOST_HUGEPAGE": "0", "CNT_HOST_PREFAULT": "0"}),
+    ("2 pipeline slots (rounds 1-2)", {"CNT_HOST_SLOTS": "2"}),
+    ("4 pipeline slots", {"CNT_HOST_SLOTS": "4"}),
+    ("3 slots, 8 copy threads", {"CNT_HOST_COPY_THREADS": "8"}),
+    ("4 slots, 8 copy threads", {"CNT_HOST_SLOTS": "4", "CNT_HOST_COPY_THREADS": "8"}),
+    ("3 slots, 2 copy threads", {"CNT_HOST_COPY_THREADS": "2"}),
 ]
 
 
@@ -95,13 +100,15 @@ if __name__ == "__main__":
     ap.add_argument("--log2-nt", type=int, default=30)
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--settings", default="", help="comma list of indices into SETTINGS (default: all)")
     a = ap.parse_args()
     if a.child:
         child(a.log2_nt, a.reps)
         sys.exit(0)
-    for name, env in SETTINGS:
+    picked = [SETTINGS[int(i)] for i in a.settings.split(",") if i] or SETTINGS
+    for name, env in picked:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--log2-nt", str(a.log2_nt), "--reps", str(a.reps)],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        print(json.dumps({"setting": name, "env": env, "log2_nt": a.log2_nt, "rows": json.loads(line[-1]) if line else None,
+        print(json.dumps({"setting": name, "env": env, "log2_nt": a.log2_nt, "cpus": len(os.sched_getaffinity(0)), "rows": json.loads(line[-1]) if line else None,
                           "error": None if line else r.stderr[-400:]}), flush=True)

@@ -187,6 +187,44 @@ __global__ __launch_bounds__(BLOCK) void k_r1w4(const uint8_t* __restrict__ in, 
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, v), rout, (u * BLOCK + threadIdx.x) * 16, 0, SAUX);
     }
 }
+// decode's access shape WITH decode's arithmetic applied R times in a dependent chain (R = 1 is the shipped kernel's
+// work; 2 and 4 ask whether the VALU time of a wave is on the critical path of this stream: the waves are resident
+// under a cap, so every cycle a wave spends computing is a cycle its slot has no memory request in flight)
+template <int BLOCK, int U, int C, int LAUX, int SAUX, int R>
+__global__ __launch_bounds__(BLOCK) void k_r1w4_arith(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t xs) {
+    constexpr uint32_t TILE_OUT = BLOCK * U * 16, TILE_IN = TILE_OUT / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN), rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    uint32_t x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (u * BLOCK + threadIdx.x) * 4, 0, LAUX);
+    touch_residency_pad(n_tiles, x[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        u32x4 v = dec4(x[u]);
+#pragma unroll
+        for (int r = 1; r < R; ++r) v = dec4(v.x ^ v.y ^ v.z ^ v.w);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, v), rout, (u * BLOCK + threadIdx.x) * 16, 0, SAUX);
+    }
+}
+// encode's access shape with encode's arithmetic applied R times
+template <int BLOCK, int U, int C, int LAUX, int SAUX, int R>
+__global__ __launch_bounds__(BLOCK) void k_r4w1_arith(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t xs) {
+    constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN), rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * BLOCK + threadIdx.x) * 16, 0, LAUX));
+    touch_residency_pad(n_tiles, v[0].x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        uint32_t c = enc16<false>(v[u]);
+#pragma unroll
+        for (int r = 1; r < R; ++r) c = enc16<false>(u32x4{c, c ^ v[u].y, c ^ v[u].z, c ^ v[u].w});
+        __builtin_amdgcn_raw_buffer_store_b32(c, rout, (u * BLOCK + threadIdx.x) * 4, 0, SAUX);
+    }
+}
 }  // namespace shipped
 
 // kind 0 read-only (1024 thr x 1 load, nt) | 1 copy 1:1 (256 thr x 1, ld=nt st=sc0|sc1|nt) |
@@ -208,6 +246,13 @@ extern "C" int probe_shipped(int kind, const void* a, void* b, size_t bytes, voi
         case 2: { const uint32_t t = (uint32_t)(bytes / (64 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r4w1<64, 2, 2, kNT, kAll>), dim3(t), dim3(64), lds_for_cap(23), s, pa, pb, t, xs); break; }
         case 3: { const uint32_t t = (uint32_t)(bytes / (128 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r1w4<128, 2, 4, 0, kAll>), dim3(t), dim3(128), lds_for_cap(13), s, pa, pb, t, xs); break; }
         case 4: { const uint32_t t = (uint32_t)(bytes / (256 * 16)); hipLaunchKernelGGL((shipped::k_write<256, 1, kAll>), dim3(t), dim3(256), 0, s, pb, t); break; }
+        // kinds 10 + R / 20 + R: the 1:4 / 4:1 shapes with the codec's own arithmetic applied R = 1, 2, 4 times (dependent chain)
+#define CNT_P14(R) { const uint32_t t = (uint32_t)(bytes / (128 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r1w4_arith<128, 2, 4, 0, kAll, R>), dim3(t), dim3(128), lds_for_cap(13), s, pa, pb, t, xs); break; }
+#define CNT_P41(R) { const uint32_t t = (uint32_t)(bytes / (64 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r4w1_arith<64, 2, 2, kNT, kAll, R>), dim3(t), dim3(64), lds_for_cap(23), s, pa, pb, t, xs); break; }
+        case 11: CNT_P14(1) case 12: CNT_P14(2) case 14: CNT_P14(4) case 18: CNT_P14(8)
+        case 21: CNT_P41(1) case 22: CNT_P41(2) case 24: CNT_P41(4) case 28: CNT_P41(8)
+#undef CNT_P14
+#undef CNT_P41
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t pack16(u32x4 q) {
 template <int MODE>
 __global__ __launch_bounds__(64) void enc12(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
     extern __shared__ uint32_t pad[];
-    const uint64_t t = tile_of_block<2>(blockIdx.x, n_tiles);
+    const uint64_t t = tile_of_block<2>(blockIdx.x, (uint32_t)n_tiles, 3 /* log2 of the 8 XCDs of an MI355X in SPX mode */);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * 2048, 2048);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * 512, 512);
     const uint32_t tid = threadIdx.x;

@@ -143,14 +143,22 @@ __device__ __forceinline__ uint32_t enc16(u32x4 q) {
 // b | b<<6 | b<<12 | b<<18 puts code k at bits 8k..8k+1 (the spread the
 // reference does with a carry-less multiply, n_to_bits.rs:357-365,381-384);
 // v_perm_b32 is then a 4-entry byte LUT: code -> "ACTG" (n_to_bits.rs:23-30).
+// Cost matters here, unlike in encode: the 1:4 stream is bound by the lifetime of its resident waves, and the
+// arithmetic-scaling probes (bench/probes.hip kinds 11..18, profiles/r03_ab_arith_*.jsonl) show decode's time growing
+// with every VALU instruction between the load's return and the store (x1 = +2.2 % over the arithmetic-free stream =
+// exactly this kernel's gap to its probe; encode is flat up to x4).  So the spread is spelled to need 4 instructions
+// per output dword instead of 5: the byte extraction rides in the SDWA operand select of a v_mul_u32_u24 by 0x1001
+// (b | b<<12: the two copies are 12 >= 8 bits apart, so the product has no carries), one v_lshl_or_b32 by 6 brings
+// codes 1 and 3 to bits 8..9 and 24..25, one v_and_b32 masks, v_perm_b32 looks up.  (A single multiply b * 0x41041 is
+// NOT the same thing: copies 6 bits apart overlap, and where OR ignores the overlap ADD carries into the bits the
+// mask keeps -- tried, 104 GPU tests said no.)
 __device__ __forceinline__ uint32_t dec1(uint32_t b /* 0..255 */) {
-#ifdef CNT_DEC_SHIFT_OR  // round 1-2 form: two shift-ORs (4-5 VALU per packed byte incl. the byte extraction)
+#ifdef CNT_DEC_SHIFT_OR  // rounds 1-2: extract, two shift-ORs, mask (5 VALU per output dword)
     uint32_t t = (b << 6) | b;
     uint32_t sel = ((t << 12) | t) & 0x03030303u;
 #else
-    // b * 0x41041 = b | b<<6 | b<<12 | b<<18 in ONE full-rate v_mul_u32_u24 (both factors < 2^24); with the byte
-    // extraction folded into the multiply's SDWA operand select that is 3 VALU per packed byte: mul, and, perm
-    uint32_t sel = __umul24(b, 0x41041u) & 0x03030303u;
+    uint32_t u = __umul24(b, 0x1001u);             // b at bits 0..7 and 12..19
+    uint32_t sel = ((u << 6) | u) & 0x03030303u;   // codes at bits 0..1, 8..9, 16..17, 24..25
 #endif
     return __builtin_amdgcn_perm(0u, 0x47544341u /* 'A','C','T','G' = bytes 0..3 */, sel);
 }

@@ -36,10 +36,11 @@ namespace n_to_bits {
 
 /// Encode {A,T/U,C,G} -> {00,10,01,11}, 32 nt per u64, LSB first (n_to_bits.rs:34-47 and the
 /// four SIMD siblings).  `strict_lut` selects n_to_bits_lut's table semantics for bytes outside
-/// the alphabet (they encode as 0) instead of the SIMD variants' (byte>>1)&3.
-inline std::vector<uint64_t> n_to_bits_hip(const uint8_t* n, size_t len, bool strict_lut = false) {
+/// the alphabet (they encode as 0) instead of the SIMD variants' (byte>>1)&3; `tail_lut` is the SIMD variants to
+/// the letter: bit extraction on whole 32-nt blocks, the table on the final partial word (n_to_bits.rs:109-111).
+inline std::vector<uint64_t> n_to_bits_hip(const uint8_t* n, size_t len, bool strict_lut = false, bool tail_lut = false) {
     std::vector<uint64_t> out(cnt_words_for(len));
-    detail::check(cnt_n_to_bits_ex(n, len, out.data(), out.size(), strict_lut ? CNT_STRICT_LUT : 0u));
+    detail::check(cnt_n_to_bits_ex(n, len, out.data(), out.size(), (strict_lut ? CNT_STRICT_LUT : 0u) | (tail_lut ? CNT_TAIL_LUT : 0u)));
     return out;
 }
 inline std::vector<uint64_t> n_to_bits_hip(const std::vector<uint8_t>& n) { return n_to_bits_hip(n.data(), n.size()); }

@@ -256,7 +256,8 @@ int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xc
  *                                decode 194 -> 72-91 ms); the advice changes the caller's VMA flags for good
  *                                (possible VMA split, huge-page RSS) -- set 0 if that is not wanted
  *   CNT_HOST_PREFAULT=0          do NOT fault the pages of large outputs in ahead of the copy-out (helper threads,
- *                                MADV_POPULATE_WRITE with a touch fallback); CNT_HOST_PREFAULT_THREADS (default 8)
+ *                                an atomic add-0 per page: faults without changing a byte); CNT_HOST_PREFAULT_THREADS (default 16 / 8 / 4 by CPU
+ *                                count); joined before the call returns
  *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
  *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy threads summed over all devices (default 32) */
 

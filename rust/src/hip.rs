@@ -19,6 +19,7 @@ extern "C" {
     fn cnt_n_to_bits_ex(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, flags: c_uint) -> c_int;
     fn cnt_bits_to_n(bits: *const u64, words: usize, len: usize, out: *mut u8) -> c_int;
     fn cnt_n_to_bits2(n: *const u8, n_len: usize, out: *mut u64, out_words: usize) -> c_int;
+    fn cnt_n_to_bits2_ex(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, flags: c_uint) -> c_int;
     fn cnt_bits_to_n2(bits: *const u64, words: usize, len: usize, out: *mut u8) -> c_int;
     fn cnt_n_to_bits_sharded(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, ndev: c_int) -> c_int;
     fn cnt_bits_to_n_sharded(bits: *const u64, words: usize, len: usize, out: *mut u8, ndev: c_int) -> c_int;
@@ -41,6 +42,7 @@ extern "C" {
 }
 
 const CNT_STRICT_LUT: c_uint = 1;
+const CNT_TAIL_LUT: c_uint = 4;
 
 fn check(status: c_int) {
     if status != 0 {
@@ -73,6 +75,18 @@ pub fn n_to_bits_hip_strict(n: &[u8]) -> Vec<u64> {
     res
 }
 
+/// `n_to_bits_{pext,shift,movemask,mul}` to the letter, on ANY bytes at any length: bit extraction on whole 32-nt
+/// blocks, `BYTE_LUT` on the final partial word (`n_to_bits.rs:109-111,160-162,201-203,253-255`).
+pub fn n_to_bits_hip_simd_exact(n: &[u8]) -> Vec<u64> {
+    let words = unsafe { cnt_words_for(n.len()) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    unsafe {
+        check(cnt_n_to_bits_ex(n.as_ptr(), n.len(), res.as_mut_ptr(), words, CNT_TAIL_LUT));
+        res.set_len(words);
+    }
+    res
+}
+
 /// Decode pairs of bits from packed 64-bit integers on the GPU (`n_to_bits.rs:51`).
 pub fn bits_to_n_hip(bits: &[u64], len: usize) -> Vec<u8> {
     if len > (bits.len() << 5) {
@@ -92,6 +106,18 @@ pub fn n_to_bits2_hip(n: &[u8]) -> Vec<u64> {
     let mut res: Vec<u64> = Vec::with_capacity(words);
     unsafe {
         check(cnt_n_to_bits2(n.as_ptr(), n.len(), res.as_mut_ptr(), words));
+        res.set_len(words);
+    }
+    res
+}
+
+/// `n_to_bits2_pext` to the letter on any bytes: its low-3-bit table up to word `(len - 5) / 27`, `BYTE_LUT` from there
+/// on (`n_to_bits2.rs:120,179-185`).
+pub fn n_to_bits2_hip_pext_exact(n: &[u8]) -> Vec<u64> {
+    let words = unsafe { cnt_words2_for(n.len()) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    unsafe {
+        check(cnt_n_to_bits2_ex(n.as_ptr(), n.len(), res.as_mut_ptr(), words, CNT_TAIL_LUT));
         res.set_len(words);
     }
     res

@@ -290,3 +290,51 @@ def test_single_process_sharded_bench_script(alias):
     assert j["partition"] == [[k << 28, (k + 1) << 28] for k in range(4)]
     assert len(j["shard_ms"]) == 4 and all(m > 0 for m in j["shard_ms"]) and j["aggregate_gnts"] > 100 and j["decode_aggregate_gnts"] > 100
     assert all(d["device_index"] == 0 for d in j["devices"])
+
+
+def test_sharded_dev_wrappers_validate_their_lists(L):
+    """the Python wrappers of cnt_*_sharded_dev hand ctypes arrays of len(shards) entries to the C
+    side, which runs shard k on device k % visible unconditionally -- a shorter `outs` / `lengths` list made the library
+    read past the arrays, a tensor on another device reached the kernel as a foreign pointer.  Both are ValueErrors
+    now, before anything is enqueued."""
+    import torch
+
+    from cute_nucleotides_amd import _lib, sharding
+
+    d = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    w = torch.zeros(128, dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        sharding.n_to_bits_sharded_dev([d, d], outs=[w])  # one output for two shards
+    with pytest.raises(ValueError):
+        sharding.bits_to_n_sharded_dev([w], [4096, 4096])  # two lengths for one shard
+    with pytest.raises(ValueError):
+        sharding.bits_to_n_sharded_dev([w, w], [4096, 4096], outs=[d])
+    if torch.cuda.device_count() == 1:
+        # two shards, one device, no test support switched on: the placement check passes (k % 1 == 0) and the library refuses
+        assert L.cnt_test_alias_devices(0) == 0
+        with pytest.raises(_lib.CuteNtError) as e:
+            sharding.n_to_bits_sharded_dev([d, d])
+        assert e.value.status == _lib.CNT_ENODEV
+    else:
+        other = torch.zeros(4096, dtype=torch.uint8, device="cuda:1")
+        with pytest.raises(ValueError):
+            sharding.n_to_bits_sharded_dev([other, d])  # shard 0 must live on device 0
+    (bits,) = sharding.n_to_bits_sharded_dev([d])
+    assert bits.numel() == 128 and int(bits.abs().sum().item()) == 0  # zero bytes -> code 0
+
+
+def test_chip_info_is_what_the_launchers_use(L):
+    """CU count, LDS per CU and XCD count come from the device (hipDeviceGetAttribute), not from
+    literals; on an MI355X in SPX mode they are 256 / 160 KiB / 8."""
+    import ctypes
+
+    import torch
+
+    cus, lds, xcds = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    assert L.cnt_chip_info(0, ctypes.byref(cus), ctypes.byref(lds), ctypes.byref(xcds)) == 0
+    props = torch.cuda.get_device_properties(0)
+    assert cus.value == props.multi_processor_count and cus.value >= 1
+    assert lds.value >= 65536 and xcds.value >= 1 and (xcds.value & (xcds.value - 1)) == 0
+    if "MI355" in props.name and cus.value == 256:
+        assert (lds.value, xcds.value) == (163840, 8)
+    assert L.cnt_chip_info(torch.cuda.device_count(), None, None, None) != 0
