@@ -33,6 +33,17 @@ rows = [
     ("`configs[3]`: 64 GiB, two passes", tb(k3.get("achieved_GBs", 0)), "%.3f" % k3.get("frac", 0), "—"),
     ("`configs[4]`: one GPU's 2^35-nt shard, encode", tb(1.25 * s4["per_gpu_gnts"]["min"]), "%.3f (read view %.3f)" % (s4["per_gpu_frac"]["min"], s4["per_gpu_read_view_frac"]["min"]), "—"),
 ]
+rag = cfg.get("ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)")
+if rag and "launches_per_call" in rag:  # round 3: one launch per call, 10 launches queued per event pair
+    rows.append(("ragged 2^30 − 19 nt, encode / decode (ONE launch each; time relative to the aligned 2^30)", "—", "%.3f / %.3f" % (rag["encode_frac"], rag["decode_frac"]),
+                 "×%.3f / ×%.3f" % (rag["encode_vs_aligned_2p30"], rag["decode_vs_aligned_2p30"])))
+if "codec5" in j and "encode" in j["codec5"]:
+    c5 = j["codec5"]
+    rows.append(("5-letter codec (1.296 B/nt), encode / decode", "%s / %s" % (tb(c5["encode"]["achieved_GBs"]), tb(c5["decode"]["achieved_GBs"])),
+                 "%.3f / %.3f" % (c5["encode"]["frac"], c5["decode"]["frac"]), "—"))
+    po = j["packed_ops"]
+    rows.append(("packed-domain ops: hamming / complement / reverse complement / validate", " / ".join(tb(po[k]["achieved_GBs"]) for k in ("hamming", "complement", "reverse_complement", "validate")),
+                 " / ".join("%.3f" % po[k]["frac"] for k in ("hamming", "complement", "reverse_complement", "validate")), "—"))
 print("| 2^34 nt, one MI355X | TB/s | of 8 TB/s | of its own no-arithmetic ceiling |")
 print("|---|---|---|---|")
 for row in rows:
@@ -45,3 +56,6 @@ if cb:
     x = j["host_tier"]["crossover_vs_one_cpu_thread"]
     for k, v in x.items():
         print("crossover", k, v["host_tier_ahead_from"])
+    h = j["host_tier"]
+    if "pcie_ceiling" in h:
+        print("pcie", h["pcie_ceiling"], {k: v for k, v in h.items() if k.startswith(("frac_of_pcie", "fresh_over"))})

@@ -41,14 +41,24 @@ def test_stats_and_crossover():
     assert bench.gbs(8e12, 1000.0) == 8000.0
 
 
-def test_design_table_is_generated_from_the_committed_line():
-    line = os.path.join(ROOT, "profiles", "r02_bench_final.json")
+import pytest
+
+
+@pytest.mark.parametrize("tag", ["r02", "r03"])
+def test_design_table_is_generated_from_the_committed_line(tag):
+    line = os.path.join(ROOT, "profiles", tag + "_bench_final.json")
     j = json.load(open(line))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "design_table.py"), line], capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stderr
     table = out.stdout.split("\n\n")[0]
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    assert table in design, "DESIGN.md's round-2 table is not the committed bench line's numbers: re-run bench/design_table.py"
+    assert table in design, "DESIGN.md's %s table is not the committed bench line's numbers: re-run bench/design_table.py" % tag
+    if tag == "r03":  # round 3's line: the blocks VERDICT r02 asked for are on it, verified in-run
+        assert j["codec5"]["verified"] is True and j["packed_ops"]["verified"] is True
+        rag = j["configs"]["ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)"]
+        assert rag["launches_per_call"] == 1 and rag["encode_vs_aligned_2p30"] < 1.01 and rag["decode_vs_aligned_2p30"] < 1.01
+        h = j["host_tier"]
+        assert h["pcie_ceiling"]["h2d_GiBs"] > 40 and min(v for k, v in h["frac_of_pcie_ceiling_at_2^30"].items() if "reused" in k) > 0.8
     # the line itself is internally consistent
     r = j["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic_source"].startswith("measured by this run")
