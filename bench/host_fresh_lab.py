@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Host tier into FRESH outputs (the literal `-> Vec<u8>` drop-in: the reference allocates inside the timed call,
 benches/bench_n_to_bits.rs:6-7) against reused outputs, under the library's environment knobs -- one child process
-per setting (the knobs are read once per process).
+per setting (the knobs are read once per process).  (profiles/r03_host_fresh_lab.jsonl and r03_host_pipeline_slots.jsonl
+were produced by an earlier version of this script, which also had rows for the fault-in helper team that round 3 built,
+measured and removed: CNT_HOST_PREFAULT / CNT_HOST_PREFAULT_THREADS in their `env` columns.)
 
     python bench/host_fresh_lab.py [--log2-nt 30] [--reps 8]
 
@@ -20,19 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SETTINGS = [
-    ("default (hugepage advice + prefault team, 3 pipeline slots)", {}),
-    ("CNT_HOST_PREFAULT=0 (round 2: hugepage advice only)", {"CNT_HOST_PREFAULT": "0"}),
-    ("prefault team of 4", {"CNT_HOST_PREFAULT_THREADS": "4"}),
-    ("prefault team of 16", {"CNT_HOST_PREFAULT_THREADS": "16"}),
-    ("prefault team of 8, 8 copy threads", {"CNT_HOST_COPY_THREADS": "8"}),
-    ("no prefault, 8 copy threads", {"CNT_HOST_PREFAULT": "0", "CNT_HOST_COPY_THREADS": "8"}),
-    ("prefault team of 8, no hugepage advice", {"CNT_HOST_HUGEPAGE": "0"}),
-    ("neither (round 1)", {"CNT_HOST_HUGEPAGE": "0", "CNT_HOST_PREFAULT": "0"}),
+    ("default (3 pipeline slots, 4 copy threads / 8 for copy-outs into fresh pages, no huge-page advice)", {}),
+    ("with huge-page advice (rounds 2's default)", {"CNT_HOST_HUGEPAGE": "1"}),
     ("2 pipeline slots (rounds 1-2)", {"CNT_HOST_SLOTS": "2"}),
     ("4 pipeline slots", {"CNT_HOST_SLOTS": "4"}),
-    ("3 slots, 8 copy threads", {"CNT_HOST_COPY_THREADS": "8"}),
-    ("4 slots, 8 copy threads", {"CNT_HOST_SLOTS": "4", "CNT_HOST_COPY_THREADS": "8"}),
-    ("3 slots, 2 copy threads", {"CNT_HOST_COPY_THREADS": "2"}),
+    ("2 copy threads (4 into fresh pages)", {"CNT_HOST_COPY_THREADS": "2"}),
+    ("8 copy threads (16 into fresh pages)", {"CNT_HOST_COPY_THREADS": "8"}),
 ]
 
 
@@ -89,7 +84,7 @@ def child(log2_nt, reps):
         rows[name] = {"ms": round(dt * 1e3, 3), "GiBs": round(m / dt / 2**30, 2)}
     keep.clear()
     out = np.empty(m, dtype=np.uint8)
-    assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0 and np.array_equal(out, n)  # a prefaulted call still decodes correctly
+    assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0 and np.array_equal(out, n)
     rows["fresh_over_reused"] = {"n_to_bits_hip": round(rows["n_to_bits_hip fresh"]["ms"] / rows["n_to_bits_hip reused"]["ms"], 3),
                                  "bits_to_n_hip": round(rows["bits_to_n_hip fresh"]["ms"] / rows["bits_to_n_hip reused"]["ms"], 3)}
     print(json.dumps(rows))

@@ -151,7 +151,6 @@ int cnt_device_numa_node(int device, int* node) {
 }
 
 static int release_thread_ctx() {
-    t_ctx.prefault.stop();
     t_ctx.pool.stop();
     for (auto& kv : t_ctx.per_device) kv.second.release();
     t_ctx.per_device.clear();

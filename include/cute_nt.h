@@ -247,17 +247,15 @@ const char *cnt_tuning_name(const char *key, int value);
 int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xcds);
 
 /* ---- environment variables the host tiers read (all optional) -------------------
- *   CNT_HOST_COPY_THREADS        staging-copy threads per calling thread (default 4, 1 = none)
+ *   CNT_HOST_COPY_THREADS        staging-copy threads per calling thread (default 4, 1 = none); copy-outs into outputs
+ *                                whose pages do not exist yet (a fresh Vec) use twice as many
+ *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 3, 2..4)
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
- *   CNT_HOST_HUGEPAGE=0          do NOT madvise(MADV_HUGEPAGE) the 2-MiB-aligned interior of outputs >= 8 MiB.
- *                                The default advises: a fresh Vec's pages are then faulted in 2-MiB units (a 1-GiB
- *                                decode 194 -> 72-91 ms); the advice changes the caller's VMA flags for good
- *                                (possible VMA split, huge-page RSS) -- set 0 if that is not wanted
- *   CNT_HOST_PREFAULT=0          do NOT fault the pages of large outputs in ahead of the copy-out (helper threads,
- *                                an atomic add-0 per page: faults without changing a byte); CNT_HOST_PREFAULT_THREADS (default 16 / 8 / 4 by CPU
- *                                count); joined before the call returns
+ *   CNT_HOST_HUGEPAGE=1          madvise(MADV_HUGEPAGE) the 2-MiB-aligned interior of outputs >= 8 MiB (OFF by default
+ *                                since round 3: it changes the caller's VMA flags for good, and with the fresh-page
+ *                                copy-out on eight threads it no longer buys anything)
  *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
  *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy threads summed over all devices (default 32) */
 
