@@ -31,6 +31,7 @@ ap.add_argument("--decode-variants", default="", help="comma list: extra rows of
 ap.add_argument("--encode-variants", default="")
 ap.add_argument("--probes", action="store_true", help="also time bench/libcnt_probes.so's 4:1 and 1:4 no-arithmetic streams")
 ap.add_argument("--arith", action="store_true", help="with --probes: the 4:1 / 1:4 streams with the codec's arithmetic applied 1, 2, 4, 8 times")
+ap.add_argument("--packed-ops", action="store_true", help="also time hamming / complement / validate of every library")
 ap.add_argument("--queue", type=int, default=1, help="launches per event pair (1 = isolated launches)")
 a = ap.parse_args()
 
@@ -45,6 +46,9 @@ def load(path):
     L.cnt_fill_random_acgt_dev.argtypes = [_vp, _sz, _sz, ctypes.c_uint64, _vp]
     L.cnt_count_mismatch_dev.argtypes = [_vp, _vp, _sz, _vp, _vp]
     L.cnt_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.cnt_hamming_dev.argtypes = [_vp, _vp, _sz, _vp, _vp]
+    L.cnt_complement_dev.argtypes = [_vp, _sz, _vp, _vp]
+    L.cnt_validate_dev.argtypes = [_vp, _sz, _u, _vp, _vp]
     return L
 
 
@@ -64,6 +68,17 @@ for name, L in libs:
     rows.append((name, "encode", lambda L=L: L.cnt_n_to_bits_dev(d_in.data_ptr(), n_len, d_pk.data_ptr(), words, 0, stream)))
     rows.append((name, "decode", lambda L=L: L.cnt_bits_to_n_dev(d_pk.data_ptr(), words, n_len, d_out.data_ptr(), 0, stream)))
     rows.append((name, "fused", lambda L=L: L.cnt_round_trip_dev(d_in.data_ptr(), n_len, d_pk.data_ptr(), words, d_out.data_ptr(), 0, stream)))
+if a.packed_ops:
+    d_pk2 = torch.empty(words, dtype=torch.int64, device=dev)
+    d_acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    assert libs[0][1].cnt_n_to_bits_dev(d_in.data_ptr(), n_len, d_pk.data_ptr(), words, 0, stream) == 0
+    assert libs[0][1].cnt_fill_random_acgt_dev(d_out.data_ptr(), 0, n_len, 0xBEEF, stream) == 0
+    assert libs[0][1].cnt_n_to_bits_dev(d_out.data_ptr(), n_len, d_pk2.data_ptr(), words, 0, stream) == 0
+    torch.cuda.synchronize()
+    for name, L in libs:  # these rows must not run interleaved with encode / decode rows of the same buffers: use --packed-ops alone
+        rows.append((name, "hamming", lambda L=L: L.cnt_hamming_dev(d_pk.data_ptr(), d_pk2.data_ptr(), n_len, d_acc.data_ptr(), stream)))
+        rows.append((name, "validate", lambda L=L: L.cnt_validate_dev(d_in.data_ptr(), n_len, 0, d_acc.data_ptr() + 8, stream)))
+    rows = [r for r in rows if r[1] in ("hamming", "validate")]
 L0 = libs[0][1]
 for key, spec in (("decode", a.decode_variants), ("encode", a.encode_variants)):
     for v in [int(x) for x in spec.split(",") if x]:
@@ -102,7 +117,7 @@ for r in range(a.rounds):
 
 # the last writer of d_pk / d_out was some library's encode / decode of d_in: a final round trip check
 cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-for name, L in libs:
+for name, L in ([] if a.packed_ops else libs):
     assert L.cnt_n_to_bits_dev(d_in.data_ptr(), n_len, d_pk.data_ptr(), words, 0, stream) == 0
     assert L.cnt_bits_to_n_dev(d_pk.data_ptr(), words, n_len, d_out.data_ptr(), 0, stream) == 0
     cnt.zero_()
@@ -112,7 +127,7 @@ for name, L in libs:
 base = {}
 for lab, op, _ in rows:
     v = ms[(lab, op)]
-    bytes_moved = (2.25 if op == "fused" else 1.25) * n_len
+    bytes_moved = {"fused": 2.25, "hamming": 0.5, "validate": 1.0}.get(op, 1.25) * n_len
     med = statistics.median(v)
     base.setdefault(op, med)
     print(json.dumps({"lib": lab, "op": op, "nt": n_len, "queue": a.queue, "ms_mean": round(statistics.fmean(v), 4), "ms_median": round(med, 4), "ms_min": round(min(v), 4),

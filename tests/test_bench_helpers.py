@@ -64,3 +64,21 @@ def test_design_table_is_generated_from_the_committed_line(tag):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic_source"].startswith("measured by this run")
     assert abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1) < 1e-3
     assert j["verified"] is True and j["n_gpus"] == 1 and j["ranks"][0]["pci_bus_id"]
+
+
+def test_bench_refuses_cleanly_without_a_gpu():
+    """no CPU fallback anywhere: on a box without a HIP device both launch forms of bench.py stop with one clear line
+    (no traceback, nothing on stdout) -- including `--gpus N` without a launcher, which used to stop for a different
+    reason ("needs a torch.distributed.run launch") before it had looked for devices at all"""
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("this box has a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for extra in ([], ["--gpus", "2"], ["--gpus", "8"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"] + extra,
+                             capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+        assert out.returncode != 0 and out.stdout.strip() == "", (extra, out.stdout[-300:])
+        assert "no HIP device visible" in out.stderr and "Traceback" not in out.stderr, (extra, out.stderr[-600:])
