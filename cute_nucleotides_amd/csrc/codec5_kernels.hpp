@@ -168,51 +168,87 @@ __device__ __forceinline__ void decode27(uint32_t lo, uint32_t hi, uint32_t (&b)
     b[6] = __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x47544341u, ab | (cc << 16) | 0x0C000000u);
 }
 
+// One packed word from byte loads, any alignment, any length (missing digits = 0, n_to_bits2.rs:58-70); `lut` = BYTE_LUT
+// semantics for THIS word (CNT_STRICT_LUT everywhere; CNT_TAIL_LUT from the word where n_to_bits2_pext hands over to
+// n_to_bits2_lut, n_to_bits2.rs:120,179-185).
+__device__ __forceinline__ uint64_t encode2_word_bytes(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t w, bool lut) {
+    const uint64_t i0 = w * 27;
+    const int m = (n_len - i0) < 27 ? (int)(n_len - i0) : 27;
+    uint32_t c[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * d + j;
+            if (k < 27 && k < m) x |= (uint32_t)n[i0 + k] << (8 * j);
+        }
+        c[d] = lut ? code5_strict(x) : code5_fast(x);  // unloaded bytes are 0 -> code 0
+    }
+    return pack27(c);
+}
+
+// min(27, len - 27w) letters of packed word w with byte stores; bits beyond `len` are ignored
+__device__ __forceinline__ void decode2_word_bytes(const uint64_t* __restrict__ bits, uint64_t len, uint8_t* __restrict__ out, uint64_t w) {
+    const uint64_t i0 = w * 27;
+    const uint64_t word = bits[w];
+    const int m = (len - i0) < 27 ? (int)(len - i0) : 27;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        uint32_t l = letters5(digits3((uint32_t)(word >> (7 * t)) & 0x7Fu));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (3 * t + j < m) out[i0 + 3 * t + j] = (uint8_t)(l >> (8 * j));
+    }
+}
+
 // ---------------------------------------------------------------------------
-// Generic kernels: one thread per word, byte accesses, any alignment/length.
+// Generic kernels: one thread per word, byte accesses, any alignment/length.  Inputs below one tile, small ragged
+// inputs, and the edges of the multi-wave variants; the default (one-wave) tile kernels carry their edges themselves.
 // ---------------------------------------------------------------------------
-// lut_from: words >= lut_from take BYTE_LUT semantics (CNT_TAIL_LUT: where n_to_bits2_pext hands over to
-// n_to_bits2_lut, n_to_bits2.rs:120,179-185); kNoLutWord = none.
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits2_generic(const uint8_t* __restrict__ n, uint64_t n_len,
                                                              uint64_t* __restrict__ out, uint64_t first_word,
                                                              uint64_t n_words, uint64_t lut_from) {
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words;
-         w += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t i0 = w * 27;
-        const int m = (n_len - i0) < 27 ? (int)(n_len - i0) : 27;
-        const bool lut = STRICT || w >= lut_from;
-        uint32_t c[7];
-#pragma unroll
-        for (int d = 0; d < 7; ++d) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * d + j;
-                if (k < 27 && k < m) x |= (uint32_t)n[i0 + k] << (8 * j);
-            }
-            c[d] = lut ? code5_strict(x) : code5_fast(x);  // unloaded bytes are 0 -> code 0 (missing digits = 0, n_to_bits2.rs:58-70)
-        }
-        out[w] = pack27(c);
-    }
+         w += (uint64_t)gridDim.x * kBlock)
+        out[w] = encode2_word_bytes(n, n_len, w, STRICT || w >= lut_from);
 }
 
 __global__ __launch_bounds__(kBlock) void bits_to_n2_generic(const uint64_t* __restrict__ bits, uint64_t len,
                                                              uint8_t* __restrict__ out, uint64_t first_word,
                                                              uint64_t n_words) {
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words;
-         w += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t i0 = w * 27;
-        const uint64_t word = bits[w];
-        const int m = (len - i0) < 27 ? (int)(len - i0) : 27;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            uint32_t l = letters5(digits3((uint32_t)(word >> (7 * t)) & 0x7Fu));
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (3 * t + j < m) out[i0 + 3 * t + j] = (uint8_t)(l >> (8 * j));
-        }
+         w += (uint64_t)gridDim.x * kBlock)
+        decode2_word_bytes(bits, len, out, w);
+}
+
+// Edges in the tile kernel's own launch (codec2_kernels.hpp, EDGES): words [0, head_words) and [tail_first, words) of a
+// call, shared by the last `groups` workgroups of the launch behind their tile's stores.  One-wave workgroups only
+// (grid == tiles); the multi-wave variants keep their separate generic launches.
+struct Encode2Edges {
+    const uint8_t* n;
+    uint64_t* out;
+    uint64_t n_len, head_words, tail_first, words, lut_from;
+    uint32_t groups;
+};
+struct Decode2Edges {
+    const uint64_t* bits;
+    uint8_t* out;
+    uint64_t len, head_words, tail_first, words;
+    uint32_t groups;
+};
+template <bool STRICT>
+__device__ __forceinline__ void encode2_edges(const Encode2Edges& e, uint64_t idx, uint64_t stride) {
+    const uint64_t items = e.head_words + (e.words - e.tail_first);
+    for (uint64_t i = idx; i < items; i += stride) {
+        const uint64_t w = i < e.head_words ? i : e.tail_first + (i - e.head_words);
+        e.out[w] = encode2_word_bytes(e.n, e.n_len, w, STRICT || w >= e.lut_from);
     }
+}
+__device__ __forceinline__ void decode2_edges(const Decode2Edges& e, uint64_t idx, uint64_t stride) {
+    const uint64_t items = e.head_words + (e.words - e.tail_first);
+    for (uint64_t i = idx; i < items; i += stride) decode2_word_bytes(e.bits, e.len, e.out, i < e.head_words ? i : e.tail_first + (i - e.head_words));
 }
 
 // ---------------------------------------------------------------------------
@@ -263,7 +299,7 @@ __device__ __forceinline__ uint64_t word_from_slab(const uint32_t* my, uint32_t 
 // 512 B per wave-instruction).
 template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
 __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                               uint64_t n_wave_tiles, uint32_t xs) {
+                                                               uint64_t n_wave_tiles, uint32_t xs, Encode2Edges e) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
@@ -295,6 +331,10 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
         const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
         __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
     }
+    if constexpr (WAVES == 1) {  // grid == tiles: the launch's last e.groups workgroups share the edge words
+        if (blockIdx.x + e.groups >= n_wave_tiles)
+            encode2_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+    }
 }
 
 // WINDOW: the default shape (one wave, 2 words per lane, 3456 B in, 1 KiB out) for an input at
@@ -305,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 // offset into it.  Reads up to 127 B before and 128 B behind the tile (launcher's business).
 template <int LAUX, int SAUX, bool STRICT, int C>
 __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                        uint64_t n_wave_tiles, uint32_t phase, uint32_t xs) {
+                                                        uint64_t n_wave_tiles, uint32_t phase, uint32_t xs, Encode2Edges e) {
     constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, WIN_VECS = kWaveVecs5 * WPL + 8;
     __shared__ __attribute__((aligned(16))) uint32_t my[WIN_VECS * 4 + 4];
     const uint32_t lane = threadIdx.x;
@@ -331,6 +371,8 @@ __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restric
         const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
         __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
     }
+    if (blockIdx.x + e.groups >= n_wave_tiles)
+        encode2_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
 }
 
 // Decode: per round j, lane l loads word j*64+l (8 B, 512 B per wave-instruction), expands
@@ -341,7 +383,7 @@ __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restric
 // with WPL*108 coalesced 16-B stores.
 template <int WAVES, int WPL, int LAUX, int SAUX, int C = 1>
 __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                               uint64_t n_wave_tiles, uint32_t xs) {
+                                                               uint64_t n_wave_tiles, uint32_t xs, Decode2Edges e) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
@@ -390,6 +432,10 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
             const u32x4 o = *reinterpret_cast<const u32x4*>(my + (i * 64 + lane) * 4);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
         }
+    if constexpr (WAVES == 1) {
+        if (blockIdx.x + e.groups >= n_wave_tiles)
+            decode2_edges(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+    }
 }
 
 }  // namespace cnt

@@ -73,24 +73,30 @@ constexpr VariantDesc kDecode2Variants[] = {
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
-// Whole wave tiles only; *done_words = words covered.
+// Whole wave tiles of [d_n, d_n + n_len) plus -- for the one-wave variants, in the same (last) launch -- the edge words `e`
+// describes; *done_words = words the tiles cover (0: nothing was launched), *edges_done = whether the edges rode along
+// (the two multi-wave variants, 2 and 3, leave them to the caller's generic launches).
 template <bool STRICT>
-int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hipStream_t s, uint64_t* done_words) {
+int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, Encode2Edges e, hipStream_t s, uint64_t* done_words, bool* edges_done) {
     if (variant < 0 || variant >= kNumEncode2Variants) return 1;
     const uint64_t tile_nt = kEncode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
     const uint64_t total = n_len / tile_nt;
     *done_words = total * tile_words;
+    const bool one_wave = variant != 2 && variant != 3;
+    *edges_done = one_wave && total > 0;
+    e.tail_first = e.head_words + *done_words;
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;  // wave tiles per launch (<= 2^31-1 threads)
     const uint32_t xs = chip_info().xcd_shift;
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile_nt;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_words * 8;
+        e.groups = (one_wave && first + n == total) ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         // the static slab is 3488 B (2 words per lane) / 6944 B (4 words per lane), allocated in 512-B granules
         const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;
         const uint32_t lds = kEncode2Variants[variant].wg_cap ? lds_for_cap(kEncode2Variants[variant].wg_cap) - slab : 0u;
 #define CNT_ENC2(W, P, L, S) \
-    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs)
+    hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
         switch (variant) {
             case 0: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 1: CNT_ENC2(1, 4, kNT, kSC1); break;
@@ -101,8 +107,8 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
             case 6: case 7: case 8: case 11: case 12: case 13: case 14: case 15: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 16: case 17: case 18: case 19: case 20: CNT_ENC2(1, 4, kNT, kSC1); break;
             case 21: CNT_ENC2(1, 4, kNT, kSC0 | kSC1 | kNT); break;
-            case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
-            case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
+            case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             default: return 1;
         }
 #undef CNT_ENC2
@@ -115,22 +121,27 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, hi
 constexpr uint32_t kWindowEncode2Tile = 2 * kWaveBytes5;  // nt per tile (128 words)
 constexpr uint32_t kWindowEncode2Slack = 128;             // bytes a tile may read behind its end
 template <bool STRICT>
-void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, hipStream_t s) {
+void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, Encode2Edges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
     const uint32_t xs = chip_info().xcd_shift;
     const uint32_t lds = lds_for_cap(kEncode2Variants[0].wg_cap) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
+    e.tail_first = e.head_words + total_tiles * (kWindowEncode2Tile / 27);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        e.groups = first + n == total_tiles ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         hipLaunchKernelGGL((n_to_bits2_window<kNT, kSC1, STRICT, 1>), dim3(grid_of(n)), dim3(64), lds, s,
-                           base + first * kWindowEncode2Tile, out + first * 1024, n, phase, xs);
+                           base + first * kWindowEncode2Tile, out + first * 1024, n, phase, xs, e);
     }
 }
 
-inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t len, hipStream_t s, uint64_t* done_words) {
+inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t len, Decode2Edges e, hipStream_t s, uint64_t* done_words, bool* edges_done) {
     if (variant < 0 || variant >= kNumDecode2Variants) return 1;
     const uint64_t tile_nt = kDecode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
     const uint64_t total = len / tile_nt;
     *done_words = total * tile_words;
+    const bool one_wave = variant != 2 && variant != 3;
+    *edges_done = one_wave && total > 0;
+    e.tail_first = e.head_words + *done_words;
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
     const uint32_t xs = chip_info().xcd_shift;
     constexpr int kAll = kSC0 | kSC1 | kNT;
@@ -138,13 +149,14 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * tile_words * 8;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_nt;
+        e.groups = (one_wave && first + n == total) ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;  // static slab, see launch_encode2
         const uint32_t lds = kDecode2Variants[variant].wg_cap ? lds_for_cap(kDecode2Variants[variant].wg_cap) - slab : 0u;
 #define CNT_DEC2(W, P, L, S) \
-    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs)
+    hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
         switch (variant) {
-            case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
-            case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
+            case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
             case 2: CNT_DEC2(2, 2, 0, kAll); break;
             case 3: CNT_DEC2(4, 2, 0, kAll); break;
@@ -153,8 +165,8 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
             case 9: case 13: case 14: case 15: CNT_DEC2(1, 2, 0, kAll); break;
             case 22: case 23: case 24: case 25: case 26: CNT_DEC2(1, 4, 0, kAll); break;
-            case 27: case 28: hipLaunchKernelGGL((bits_to_n2_wave<1, 4, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
-            case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs); break;
+            case 27: case 28: hipLaunchKernelGGL((bits_to_n2_wave<1, 4, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             default: return 1;
         }
 #undef CNT_DEC2

@@ -308,3 +308,28 @@ def test_tail_lut_equals_n_to_bits2_pext_on_arbitrary_bytes(cn, oracle):
     finally:
         devutil.set_tuning("small_nt", saved)
         sharding.alias_devices(prev)
+
+
+def test_one_launch_per_call_at_any_size_and_alignment(cn, oracle, no_small_path):
+    """the 5-letter codec's default kernels carry their head words and ragged end themselves (the last workgroups of the
+    grid, behind their tile's stores -- the 2-bit codec's scheme): ONE node in a captured graph, results still the oracle's"""
+    import torch
+
+    from test_gpu_codec2 import _kernel_nodes_of
+
+    n_len = 3456 * 300 + 1234
+    host = oracle.fill_random_acgtn(n_len, 9)
+    want = oracle.n_to_bits2_lut(host)
+    want_back = oracle.bits_to_n2_lut(want, n_len)
+    ibuf = torch.zeros(n_len + 256, dtype=torch.uint8, device="cuda")
+    pbuf = torch.zeros(want.size + 64, dtype=torch.int64, device="cuda")
+    obuf = torch.zeros(n_len + 512, dtype=torch.uint8, device="cuda")
+    for io, po, oo in ((0, 0, 0), (0, 3, 0), (5, 0, 77), (64, 1, 127), (127, 7, 1), (16, 0, 16)):
+        view = ibuf[io : io + n_len]
+        view.copy_(torch.from_numpy(host))
+        packed = pbuf[po : po + want.size]
+        out = obuf[oo : oo + n_len]
+        assert _kernel_nodes_of(torch, lambda: cn.n_to_bits2_dev(view, out=packed)) == 1, (io, po)
+        assert np.array_equal(packed.cpu().numpy().view(np.uint64), want), (io, po)
+        assert _kernel_nodes_of(torch, lambda: cn.bits_to_n2_dev(packed, n_len, out=out)) == 1, (po, oo)
+        assert np.array_equal(out.cpu().numpy(), want_back), (po, oo)
