@@ -251,6 +251,26 @@ __device__ __forceinline__ void decode_edges(const DecodeEdges& e, uint64_t idx,
 }
 inline uint64_t decode_edge_items(const DecodeEdges& e) { return e.head + (e.len - e.tail_lo); }
 
+// the ragged end of a fused round trip: words [tail_first, words) with their letters -- a thread packs one word from
+// byte loads and spells the same codes back out (no thread waits for another's word)
+struct RoundTripEdges {
+    const uint8_t* n;
+    uint64_t* packed;
+    uint8_t* back;
+    uint64_t n_len, tail_first, words, lut_from;
+    uint32_t groups;
+};
+template <bool STRICT>
+__device__ __forceinline__ void round_trip_edges(const RoundTripEdges& e, uint64_t idx, uint64_t stride) {
+    for (uint64_t w = e.tail_first + idx; w < e.words; w += stride) {
+        const uint64_t acc = encode_word_bytes(e.n, e.n_len, w, STRICT || w >= e.lut_from);
+        e.packed[w] = acc;
+        const uint64_t i0 = w << 5;
+        const int m = (e.n_len - i0) < 32 ? (int)(e.n_len - i0) : 32;
+        for (int k = 0; k < m; ++k) e.back[i0 + k] = (uint8_t)(0x47544341u >> ((uint32_t)((acc >> (2 * k)) & 3u) << 3));
+    }
+}
+
 // the end of every tile kernel: the launch's last e.groups workgroups (groups <= n_tiles) share the edge items
 #define CNT_ENCODE_EDGES_TAIL(BLOCK_)                                                                                   \
     if (blockIdx.x + e.groups >= n_tiles)                                                                               \
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
 // per lane, 4 KiB of ASCII per workgroup, plain dispatch order (codec2_launch.hpp, bench/tune_lab11.hip).
 template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed,
-                                                           uint8_t* __restrict__ back, uint32_t n_tiles, uint32_t xs) {
+                                                           uint8_t* __restrict__ back, uint32_t n_tiles, uint32_t xs, RoundTripEdges e) {
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_PK = TILE_IN / 4;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
@@ -348,6 +368,8 @@ __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __rest
         __builtin_amdgcn_raw_buffer_store_b32(code, rpk, (u * BLOCK + tid) * 4, 0, SAUX);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(code)), rbk, (u * BLOCK + tid) * 16, 0, SAUX);
     }
+    if (blockIdx.x + e.groups >= n_tiles)
+        round_trip_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * BLOCK + tid, (uint64_t)e.groups * BLOCK);
 }
 
 // LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,

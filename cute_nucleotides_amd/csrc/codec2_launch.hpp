@@ -180,19 +180,22 @@ constexpr uint32_t kRoundTripDefaultCap = 8;
 // shape 0 = the default above; shape 1 = the first shipped shape (<64, 2, 2>: two loads, XCD pairs; wants cap 13),
 // two of its 2-KiB tiles per 4-KiB unit -- kept selectable (tuning key "round_trip_shape") for A/B runs
 template <bool STRICT>
-void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, hipStream_t s) {
+void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, RoundTripEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 2;  // in 4-KiB units, valid for both shapes
     const uint32_t lds = lds_for_cap(cap);
     const uint32_t xs = chip_info().xcd_shift;
+    e.tail_first = total_tiles * (kRoundTripTile / 32);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        // the ragged end (< one tile: at most 128 words) rides in the last launch
+        e.groups = first + n_tiles == total_tiles ? edge_groups(e.words - e.tail_first, 64, shape == 1 ? 2 * n_tiles : n_tiles) : 0u;
         const uint8_t* i0 = in + first * kRoundTripTile;
         uint8_t* p0 = packed + first * (kRoundTripTile / 4);
         uint8_t* b0 = back + first * kRoundTripTile;
         if (shape == 1)
-            hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(2 * n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)(2 * n_tiles), xs);
+            hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(2 * n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)(2 * n_tiles), xs, e);
         else
-            hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs);
+            hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e);
     }
 }
 

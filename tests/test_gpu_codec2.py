@@ -785,6 +785,13 @@ def test_any_size_and_alignment_is_one_launch(cn, oracle, torch_cuda, tuning):
         assert np.array_equal(packed.cpu().numpy().view(np.uint64), want), (io, po)
         assert _kernel_nodes_of(torch, lambda: cn.bits_to_n_dev(packed, n_len, out=out)) == 1, (po, oo)
         assert np.array_equal(out.cpu().numpy(), want_back), (po, oo)
+    # the fused round trip on aligned pointers: its ragged end (here 2^21 - 19 = 511 tiles of 4096 nt + 4077 nt) rides along too
+    view, packed, out = ibuf[:n_len], pbuf[:words], obuf[:n_len]
+    view.copy_(torch.from_numpy(host))
+    packed.zero_()
+    out.zero_()
+    assert _kernel_nodes_of(torch, lambda: cn.round_trip_dev(view, out_bits=packed, out_n=out)) == 1
+    assert np.array_equal(packed.cpu().numpy().view(np.uint64), want) and np.array_equal(out.cpu().numpy(), want_back)
     # shorter than one tile: the generic kernel alone, also one launch
     small = ibuf[3 : 3 + 1000]
     assert _kernel_nodes_of(torch, lambda: cn.n_to_bits_dev(small, out=pbuf[:32])) == 1

@@ -53,14 +53,20 @@ def test_two_bit_codec_fuzz(oracle, small_nt, seed):
         words = (n_len + 31) // 32
         obuf = torch.full((words + 4,), -1, dtype=torch.int64, device="cuda")
         strict = bool(rng.integers(0, 2))
-        got = cn.n_to_bits_dev(view, out=obuf[off_out:], strict_lut=strict).cpu().numpy().view(np.uint64)
+        tail = not strict and bool(rng.integers(0, 2))  # CNT_TAIL_LUT: the SIMD encoders to the letter (table on the final partial word)
+        if tail and anybytes:
+            n = n & 0x7F  # the reference indexes BYTE_LUT[128] with the tail's bytes: 7-bit input only
+            view.copy_(torch.from_numpy(n))
+        got = cn.n_to_bits_dev(view, out=obuf[off_out:], strict_lut=strict, tail_lut=tail).cpu().numpy().view(np.uint64)
         if strict or not anybytes:
             want = oracle.n_to_bits_lut(n)
+        elif tail:
+            want = oracle.n_to_bits_bitextract(n)  # bits 1..2 on whole 32-nt blocks, BYTE_LUT on the ragged end (n_to_bits.rs:96-111)
         else:  # default mode on arbitrary bytes: (byte>>1)&3 everywhere, tail included
             codes = ((n >> 1) & 3).astype(np.uint64)
             pad = np.zeros((-n_len) % 32, dtype=np.uint64)
             want = np.bitwise_or.reduce(np.concatenate([codes, pad]).reshape(-1, 32) << (np.arange(32, dtype=np.uint64) * np.uint64(2)), axis=1) if words else np.empty(0, np.uint64)
-        assert np.array_equal(got, want), (seed, n_len, off_in, off_out, strict, anybytes)
+        assert np.array_equal(got, want), (seed, n_len, off_in, off_out, strict, tail, anybytes)
         o = obuf.cpu().numpy()
         assert (o[:off_out] == -1).all() and (o[off_out + words :] == -1).all()
         # decode a random prefix of what was just packed, into an offset output
@@ -90,6 +96,11 @@ def test_five_letter_codec_fuzz(oracle, small_nt, seed):
         want = oracle.n_to_bits2_lut(n)
         got = cn.n_to_bits2_dev(view, strict_lut=bool(rng.integers(0, 2))).cpu().numpy().view(np.uint64)
         assert np.array_equal(got, want), (seed, n_len, off_in)
+        if oracle.port_cpu_ok() and n_len:  # CNT_TAIL_LUT on arbitrary 7-bit bytes == the port of n_to_bits2_pext
+            junk = rng.integers(0, 128, n_len, dtype=np.uint8)
+            view.copy_(torch.from_numpy(junk))
+            got = cn.n_to_bits2_dev(view, tail_lut=True).cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, oracle.n_to_bits2_pext(junk)), (seed, n_len, off_in, "tail_lut")
         length = int(rng.integers(0, n_len + 1))
         dout = torch.full((n_len + 80,), 0x5A, dtype=torch.uint8, device="cuda")
         off_d = int(rng.choice([0, 0, 16, 3]))

@@ -65,7 +65,7 @@ def test_2bit_codec_instruction_selection(isa):
     t, w, m = _tile(isa_digest, found, "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>")
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
     assert t["counts"]["buffer_load_dwordx4"] == 4 and t["counts"]["buffer_store_dword"] == 4 and t["counts"]["buffer_store_dwordx4"] == 4
-    assert "s_and_saveexec_b64" not in w["counts"]
+    assert "s_and_saveexec_b64" not in t["counts"]
 
 
 def test_5letter_codec_instruction_selection(isa):
