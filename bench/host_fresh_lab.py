@@ -22,8 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SETTINGS = [
-    ("default (3 pipeline slots, 4 copy threads / 8 for copy-outs into fresh pages, no huge-page advice)", {}),
-    ("with huge-page advice (rounds 2's default)", {"CNT_HOST_HUGEPAGE": "1"}),
+    ("default (huge-page advice, 3 pipeline slots, 4 copy threads / 8 for copy-outs into fresh pages)", {}),
+    ("no huge-page advice (numpy still advises its own allocations)", {"CNT_HOST_HUGEPAGE": "0"}),
     ("2 pipeline slots (rounds 1-2)", {"CNT_HOST_SLOTS": "2"}),
     ("4 pipeline slots", {"CNT_HOST_SLOTS": "4"}),
     ("2 copy threads (4 into fresh pages)", {"CNT_HOST_COPY_THREADS": "2"}),

@@ -253,9 +253,11 @@ int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xc
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
- *   CNT_HOST_HUGEPAGE=1          madvise(MADV_HUGEPAGE) the 2-MiB-aligned interior of outputs >= 8 MiB (OFF by default
- *                                since round 3: it changes the caller's VMA flags for good, and with the fresh-page
- *                                copy-out on eight threads it no longer buys anything)
+ *   CNT_HOST_HUGEPAGE=0          do NOT madvise(MADV_HUGEPAGE) the 2-MiB-aligned interior of outputs >= 8 MiB.  The default
+ *                                advises -- the one thing the library does to caller memory besides writing the result:
+ *                                a fresh malloc'd output is then faulted in, and later freed by the caller, in 2-MiB
+ *                                units (1-GiB decode into a fresh malloc: 150 -> 72-91 ms per call).  The advice changes
+ *                                the caller's VMA flags for good (possible VMA split, huge-page RSS): set 0 if unwanted
  *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
  *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy threads summed over all devices (default 32) */
 
