@@ -230,6 +230,13 @@ constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=128 U=2 xcd-quads ld=sc0|sc1 st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 24
     {"stream B=128 U=2 xcd-quads ld=sc1 st=sc0|sc1|nt, 14 wg/CU", 128 * 2 * 16, 128, 14},      // 25
     {"stream B=128 U=2 xcd-quads ld=sc1 st=sc0|sc1|nt, 12 wg/CU", 128 * 2 * 16, 128, 12},      // 26
+    // store policies under the final shape (decode is bound by the lifetime of its waves: does a store that need not
+    // be acknowledged by memory retire them earlier?)
+    {"stream B=128 U=2 xcd-quads ld=plain st=nt, 13 wg/CU", 128 * 2 * 16, 128, 13},            // 27
+    {"stream B=128 U=2 xcd-quads ld=plain st=plain, 13 wg/CU", 128 * 2 * 16, 128, 13},         // 28
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},        // 29
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},        // 30
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc1, 13 wg/CU", 128 * 2 * 16, 128, 13},           // 31
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -276,6 +283,11 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 20: case 25: case 26: CNT_DEC_STREAM(128, 2, 4, kSC1, kAll); break;
         case 23: CNT_DEC_STREAM(128, 2, 4, kSC1 | kNT, kAll); break;
         case 24: CNT_DEC_STREAM(128, 2, 4, kSC0 | kSC1, kAll); break;
+        case 27: CNT_DEC_STREAM(128, 2, 4, 0, kNT); break;
+        case 28: CNT_DEC_STREAM(128, 2, 4, 0, 0); break;
+        case 29: CNT_DEC_STREAM(128, 2, 4, 0, kSC1 | kNT); break;
+        case 30: CNT_DEC_STREAM(128, 2, 4, 0, kSC0 | kNT); break;
+        case 31: CNT_DEC_STREAM(128, 2, 4, 0, kSC1); break;
         case 21: CNT_DEC_STREAM(128, 2, 4, kNT, kAll); break;
         default: return 1;
     }
