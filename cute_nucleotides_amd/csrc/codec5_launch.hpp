@@ -37,6 +37,13 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 10 wg/CU", 4 * kWaveBytes5, 64, 10},  // 19
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1, 12 wg/CU", 4 * kWaveBytes5, 64, 12},  // 20
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc0|sc1|nt, 8 wg/CU", 4 * kWaveBytes5, 64, 8},  // 21
+    // round 3: the default shape with the store / load policies that were only ever measured together with other changes
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc0|sc1|nt, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 22
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1|nt, 15 wg/CU", 2 * kWaveBytes5, 64, 15},      // 23
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=nt, 15 wg/CU", 2 * kWaveBytes5, 64, 15},          // 24
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=sc1|nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},     // 25
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},      // 26
+    {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc0|sc1|nt, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 27
 };
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
@@ -70,6 +77,9 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt, 12 wg/CU", 4 * kWaveBytes5, 64, 12},  // 26
     {"wave-tiled 4 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 8 wg/CU", 4 * kWaveBytes5, 64, 8},  // 27
     {"wave-tiled 4 words/lane, 1 wave/wg, xcd-pairs, ld=plain st=sc0|sc1|nt, 9 wg/CU", 4 * kWaveBytes5, 64, 9},  // 28
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},   // 29
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=nt st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 30
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=sc1 st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16}, // 31
 };
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -107,6 +117,11 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
             case 6: case 7: case 8: case 11: case 12: case 13: case 14: case 15: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 16: case 17: case 18: case 19: case 20: CNT_ENC2(1, 4, kNT, kSC1); break;
             case 21: CNT_ENC2(1, 4, kNT, kSC0 | kSC1 | kNT); break;
+            case 22: case 27: CNT_ENC2(1, 2, kNT, kSC0 | kSC1 | kNT); break;
+            case 23: CNT_ENC2(1, 2, kNT, kSC1 | kNT); break;
+            case 24: CNT_ENC2(1, 2, kNT, kNT); break;
+            case 25: CNT_ENC2(1, 2, kSC1 | kNT, kSC1); break;
+            case 26: CNT_ENC2(1, 2, 0, kSC1); break;
             case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             default: return 1;
@@ -167,6 +182,9 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 22: case 23: case 24: case 25: case 26: CNT_DEC2(1, 4, 0, kAll); break;
             case 27: case 28: hipLaunchKernelGGL((bits_to_n2_wave<1, 4, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 10: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 29: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kSC1 | kNT, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 30: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 31: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kSC1, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             default: return 1;
         }
 #undef CNT_DEC2
