@@ -14,10 +14,14 @@
 // are re-entrant and callable from any thread.
 #pragma once
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../include/cute_nt.h"
@@ -25,6 +29,40 @@
 namespace cute_nucleotides {
 
 namespace detail {
+// The reference's functions allocate their result UNINITIALISED and set its length afterwards (Vec::with_capacity /
+// alloc + set_len / from_raw_parts, n_to_bits.rs:88-89,113): the output is written exactly once, by the codec.
+// std::vector<T>(n) would first zero-fill it -- single-threaded, page by page: a 1-GiB decode through this mirror cost
+// 262 ms against 85 ms for the C call into a fresh malloc (profiles/r03_bench_twin.log).  This allocator makes
+// `Vec<T>(n)` default-initialise (= leave alone) trivially constructible elements; everything else is std::allocator.
+template <class T>
+struct uninit_allocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = uninit_allocator<U>;
+    };
+    uninit_allocator() = default;
+    template <class U>
+    uninit_allocator(const uninit_allocator<U>&) noexcept {}
+    template <class U>
+    void construct(U* p) noexcept(noexcept(::new (static_cast<void*>(p)) U)) {
+        ::new (static_cast<void*>(p)) U;  // default-initialisation: no zero fill for u8 / u64
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+// Vec<T> against a plain std::vector<T> (found by ADL through the allocator's namespace)
+template <class T, class B, std::enable_if_t<!std::is_same<B, uninit_allocator<T>>::value, int> = 0>
+inline bool operator==(const std::vector<T, uninit_allocator<T>>& a, const std::vector<T, B>& b) {
+    return a.size() == b.size() && std::equal(a.begin(), a.end(), b.begin());
+}
+template <class T, class B, std::enable_if_t<!std::is_same<B, uninit_allocator<T>>::value, int> = 0>
+inline bool operator!=(const std::vector<T, uninit_allocator<T>>& a, const std::vector<T, B>& b) { return !(a == b); }
+template <class T>
+inline bool operator==(const std::vector<T>& a, const std::vector<T, uninit_allocator<T>>& b) { return b == a; }
+template <class T>
+inline bool operator!=(const std::vector<T>& a, const std::vector<T, uninit_allocator<T>>& b) { return !(b == a); }
 inline void check(int status) {
     if (status == CNT_OK) return;
     if (status == CNT_ELEN) throw std::length_error(cnt_strerror(status));  // the reference's panic
@@ -32,39 +70,46 @@ inline void check(int status) {
 }
 }  // namespace detail
 
+/// What the `*_hip` functions return: a std::vector whose elements are NOT zero-filled on construction (the
+/// reference's `Vec` with `set_len`).  Converts to a plain std::vector with `std::vector<T>(v.begin(), v.end())`.
+template <class T>
+using Vec = std::vector<T, detail::uninit_allocator<T>>;
+
 namespace n_to_bits {
 
 /// Encode {A,T/U,C,G} -> {00,10,01,11}, 32 nt per u64, LSB first (n_to_bits.rs:34-47 and the
 /// four SIMD siblings).  `strict_lut` selects n_to_bits_lut's table semantics for bytes outside
 /// the alphabet (they encode as 0) instead of the SIMD variants' (byte>>1)&3; `tail_lut` is the SIMD variants to
 /// the letter: bit extraction on whole 32-nt blocks, the table on the final partial word (n_to_bits.rs:109-111).
-inline std::vector<uint64_t> n_to_bits_hip(const uint8_t* n, size_t len, bool strict_lut = false, bool tail_lut = false) {
-    std::vector<uint64_t> out(cnt_words_for(len));
+inline Vec<uint64_t> n_to_bits_hip(const uint8_t* n, size_t len, bool strict_lut = false, bool tail_lut = false) {
+    Vec<uint64_t> out(cnt_words_for(len));
     detail::check(cnt_n_to_bits_ex(n, len, out.data(), out.size(), (strict_lut ? CNT_STRICT_LUT : 0u) | (tail_lut ? CNT_TAIL_LUT : 0u)));
     return out;
 }
-inline std::vector<uint64_t> n_to_bits_hip(const std::vector<uint8_t>& n) { return n_to_bits_hip(n.data(), n.size()); }
+template <class A>
+inline Vec<uint64_t> n_to_bits_hip(const std::vector<uint8_t, A>& n) { return n_to_bits_hip(n.data(), n.size()); }
 
 /// Decode `len` nucleotides (n_to_bits.rs:51-69 and the three SIMD siblings).
-inline std::vector<uint8_t> bits_to_n_hip(const uint64_t* bits, size_t words, size_t len) {
+inline Vec<uint8_t> bits_to_n_hip(const uint64_t* bits, size_t words, size_t len) {
     if (len > (words << 5)) detail::check(CNT_ELEN);
-    std::vector<uint8_t> out(len);
+    Vec<uint8_t> out(len);
     detail::check(cnt_bits_to_n(bits, words, len, out.data()));
     return out;
 }
-inline std::vector<uint8_t> bits_to_n_hip(const std::vector<uint64_t>& bits, size_t len) {
+template <class A>
+inline Vec<uint8_t> bits_to_n_hip(const std::vector<uint64_t, A>& bits, size_t len) {
     return bits_to_n_hip(bits.data(), bits.size(), len);
 }
 
 /// The same, cut into contiguous chunks over `ndev` GPUs (<= 0: all visible), no collective.
-inline std::vector<uint64_t> n_to_bits_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
-    std::vector<uint64_t> out(cnt_words_for(len));
+inline Vec<uint64_t> n_to_bits_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
+    Vec<uint64_t> out(cnt_words_for(len));
     detail::check(cnt_n_to_bits_sharded(n, len, out.data(), out.size(), ndev));
     return out;
 }
-inline std::vector<uint8_t> bits_to_n_hip_sharded(const uint64_t* bits, size_t words, size_t len, int ndev = 0) {
+inline Vec<uint8_t> bits_to_n_hip_sharded(const uint64_t* bits, size_t words, size_t len, int ndev = 0) {
     if (len > (words << 5)) detail::check(CNT_ELEN);
-    std::vector<uint8_t> out(len);
+    Vec<uint8_t> out(len);
     detail::check(cnt_bits_to_n_sharded(bits, words, len, out.data(), ndev));
     return out;
 }
@@ -74,33 +119,35 @@ inline std::vector<uint8_t> bits_to_n_hip_sharded(const uint64_t* bits, size_t w
 namespace n_to_bits2 {
 
 /// 5-letter codec, 3 nt -> 7 bits, 27 nt per u64 (n_to_bits2.rs:37-74, :118-189).
-inline std::vector<uint64_t> n_to_bits2_hip(const uint8_t* n, size_t len) {
-    std::vector<uint64_t> out(cnt_words2_for(len));
+inline Vec<uint64_t> n_to_bits2_hip(const uint8_t* n, size_t len) {
+    Vec<uint64_t> out(cnt_words2_for(len));
     detail::check(cnt_n_to_bits2(n, len, out.data(), out.size()));
     return out;
 }
-inline std::vector<uint64_t> n_to_bits2_hip(const std::vector<uint8_t>& n) { return n_to_bits2_hip(n.data(), n.size()); }
+template <class A>
+inline Vec<uint64_t> n_to_bits2_hip(const std::vector<uint8_t, A>& n) { return n_to_bits2_hip(n.data(), n.size()); }
 
 /// n_to_bits2.rs:78-107, :196-268.
-inline std::vector<uint8_t> bits_to_n2_hip(const uint64_t* bits, size_t words, size_t len) {
+inline Vec<uint8_t> bits_to_n2_hip(const uint64_t* bits, size_t words, size_t len) {
     if (words > SIZE_MAX / 27 || len > words * 27) detail::check(CNT_ELEN);
-    std::vector<uint8_t> out(len);
+    Vec<uint8_t> out(len);
     detail::check(cnt_bits_to_n2(bits, words, len, out.data()));
     return out;
 }
-inline std::vector<uint8_t> bits_to_n2_hip(const std::vector<uint64_t>& bits, size_t len) {
+template <class A>
+inline Vec<uint8_t> bits_to_n2_hip(const std::vector<uint64_t, A>& bits, size_t len) {
     return bits_to_n2_hip(bits.data(), bits.size(), len);
 }
 
 /// The 5-letter codec over `ndev` GPUs (shards are whole 128-word tiles), no collective.
-inline std::vector<uint64_t> n_to_bits2_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
-    std::vector<uint64_t> out(cnt_words2_for(len));
+inline Vec<uint64_t> n_to_bits2_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
+    Vec<uint64_t> out(cnt_words2_for(len));
     detail::check(cnt_n_to_bits2_sharded(n, len, out.data(), out.size(), ndev));
     return out;
 }
-inline std::vector<uint8_t> bits_to_n2_hip_sharded(const uint64_t* bits, size_t words, size_t len, int ndev = 0) {
+inline Vec<uint8_t> bits_to_n2_hip_sharded(const uint64_t* bits, size_t words, size_t len, int ndev = 0) {
     if (words > SIZE_MAX / 27 || len > words * 27) detail::check(CNT_ELEN);
-    std::vector<uint8_t> out(len);
+    Vec<uint8_t> out(len);
     detail::check(cnt_bits_to_n2_sharded(bits, words, len, out.data(), ndev));
     return out;
 }
@@ -122,9 +169,9 @@ class DeviceBuffer {
     void* data() const { return ptr_; }
     size_t size_bytes() const { return bytes_; }
     template <typename T>
-    std::vector<T> to_vector(size_t count) const {  // synchronous copy back to the host
+    Vec<T> to_vector(size_t count) const {  // synchronous copy back to the host
         if (count * sizeof(T) > bytes_) throw std::out_of_range("DeviceBuffer::to_vector");
-        std::vector<T> out(count);
+        Vec<T> out(count);
         detail::check(cnt_dev_download(out.data(), ptr_, count * sizeof(T)));
         return out;
     }
