@@ -239,7 +239,7 @@ extern "C" int probe_shipped(int kind, const void* a, void* b, size_t bytes, voi
     uint8_t* pb = static_cast<uint8_t*>(b);
     if (bytes == 0 || (bytes & 16383) || bytes > ((size_t)1 << 35)) return 1;
     constexpr int kAll = kSC0 | kSC1 | kNT;
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     switch (kind) {
         case 0: { const uint32_t t = (uint32_t)(bytes / (1024 * 16)); hipLaunchKernelGGL((shipped::k_read<1024, 1, kNT>), dim3(t), dim3(1024), 0, s, pa, pb, t); break; }
         case 1: { const uint32_t t = (uint32_t)(bytes / (256 * 16)); hipLaunchKernelGGL((shipped::k_copy<256, 1, 1, kNT, kAll>), dim3(t), dim3(256), 0, s, pa, pb, t, xs); break; }

@@ -58,6 +58,17 @@ inline const ChipInfo& chip_info() {  // of the calling thread's current device
     return table[dev];
 }
 
+// log2 of the XCD count the block -> tile maps are built for: the device's, unless the tuning key "xcd_shift" overrides it
+// (A/B runs, and the test that walks every value a partition mode could produce: the maps must be bijections for ANY value)
+inline std::atomic<int>& xcd_shift_override() {
+    static std::atomic<int> v{-1};
+    return v;
+}
+inline uint32_t xcd_shift() {
+    const int o = xcd_shift_override().load(std::memory_order_relaxed);
+    return o >= 0 ? (uint32_t)o : chip_info().xcd_shift;
+}
+
 // dynamic-LDS bytes that let `cap` workgroups (and no more) fit in a CU's LDS (160 KiB on gfx950)
 inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (chip_info().lds_per_cu / cap) / 256u * 256u : 0u; }
 
@@ -113,7 +124,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
     *done_nt = total_tiles * tile;
     e.tail_first = e.head_words + (*done_nt >> 5);
     const uint64_t per_launch = max_tiles_per_launch(kEncodeVariants[variant].block);
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     const uint32_t lds = lds_for_cap(kEncodeVariants[variant].wg_cap);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
     const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
@@ -157,7 +168,7 @@ template <bool STRICT>
 void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64);
     const uint32_t lds = lds_for_cap(23);  // doubles as the kernel's 768-B exchange slab
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     e.tail_first = e.head_words + total_tiles * (kWindowEncodeTile / 32);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
@@ -183,7 +194,7 @@ template <bool STRICT>
 void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, RoundTripEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 2;  // in 4-KiB units, valid for both shapes
     const uint32_t lds = lds_for_cap(cap);
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     e.tail_first = total_tiles * (kRoundTripTile / 32);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
@@ -249,7 +260,7 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     *done_nt = total_tiles * tile;
     e.tail_lo = e.head + *done_nt;
     const uint64_t per_launch = max_tiles_per_launch(kDecodeVariants[variant].block);
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     const uint32_t lds = lds_for_cap(kDecodeVariants[variant].wg_cap);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
     const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
@@ -302,7 +313,7 @@ constexpr uint32_t kShiftedDecodeTile = 128 * 2 * 16;
 inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, DecodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(128);
     const uint32_t lds = lds_for_cap(13);
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     e.tail_lo = e.head + total_tiles * kShiftedDecodeTile;
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;

@@ -96,7 +96,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
     *edges_done = one_wave && total > 0;
     e.tail_first = e.head_words + *done_words;
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;  // wave tiles per launch (<= 2^31-1 threads)
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
         const uint8_t* in = static_cast<const uint8_t*>(d_n) + first * tile_nt;
@@ -138,7 +138,7 @@ constexpr uint32_t kWindowEncode2Slack = 128;             // bytes a tile may re
 template <bool STRICT>
 void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, Encode2Edges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     const uint32_t lds = lds_for_cap(kEncode2Variants[0].wg_cap) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
     e.tail_first = e.head_words + total_tiles * (kWindowEncode2Tile / 27);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
@@ -158,7 +158,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
     *edges_done = one_wave && total > 0;
     e.tail_first = e.head_words + *done_words;
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
-    const uint32_t xs = chip_info().xcd_shift;
+    const uint32_t xs = xcd_shift();
     constexpr int kAll = kSC0 | kSC1 | kNT;
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;

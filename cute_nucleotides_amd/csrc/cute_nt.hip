@@ -355,6 +355,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "reduce_xi")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_xi.store(value);
+    } else if (!strcmp(key, "xcd_shift")) {
+        if (value < -1 || value > 6) return CNT_EINVAL;
+        xcd_shift_override().store(value);
     } else if (!strcmp(key, "small_nt")) {
         if (value < 0) return CNT_EINVAL;
         g_small_nt.store(value);
@@ -371,6 +374,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "encode2")) *value = g_encode2_variant.load();
     else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
     else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
+    else if (!strcmp(key, "xcd_shift")) *value = (int)xcd_shift();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
     else if (!strcmp(key, "round_trip_shape")) *value = g_round_trip_shape.load();

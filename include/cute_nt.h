@@ -234,6 +234,8 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
  * wave x four loads, plain order) / 1 (the first shipped shape: two loads, XCD pairs; pair it with cap 13); "reduce_persistent":
  * 1 (default) = hamming / validate as one launch of persistent waves, 0 = round 1's tiles + scratch + second pass, whose
  * tiles read their pages XCD-interleaved when "reduce_xi" is 1.
+ * "xcd_shift": log2 of the XCD count the block -> tile maps assume (-1 = ask the device, the default; get returns the
+ * value in effect) -- the maps are bijections for every value, only speed depends on it.
  * cnt_tuning_name returns the variant's description (NULL when out of range).
  * CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);

@@ -843,3 +843,45 @@ def test_config4_rank_shard_at_its_global_offset(cn, oracle, torch_cuda, fullsiz
         want = oracle.n_to_bits_lut(tail_n)
         got = rb[-(chunk_w) :].cpu().numpy().view(np.uint64)
         assert np.array_equal(got, want) and int(got[-1]) >> 26 == 0
+
+
+@pytest.mark.parametrize("xs", [0, 1, 2, 3, 4, 5])
+def test_tile_maps_are_bijections_for_any_xcd_count(cn, oracle, torch_cuda, xs):
+    """the XCD count is asked of the device and reaches the kernels as log2 X.  Partition modes
+    (CPX / DPX / QPX: 1 / 2 / 4 XCDs per device) cannot be switched on here, so the tuning key "xcd_shift" walks every
+    value a device could answer (and two it could not): the block -> tile maps of every kernel family -- encode pairs,
+    decode quads, fused, window / shifted twins, the 5-letter quads -- must stay bijections, i.e. results stay the
+    oracle's, including sizes whose last group of X*C tiles is ragged."""
+    from cute_nucleotides_amd import devutil
+
+    torch = torch_cuda
+    saved_small = devutil.get_tuning("small_nt")
+    devutil.set_tuning("small_nt", 0)
+    devutil.set_tuning("xcd_shift", xs)
+    try:
+        assert devutil.get_tuning("xcd_shift") == xs
+        for n_len in (2048 * 7, 4096 * 129 + 5, 2048 * (16 << xs) + 2048 * 3 + 17, (1 << 22) + 4096 * 5 + 31):
+            host = _rand_valid(n_len, 40 + xs)
+            want = oracle.n_to_bits_lut(host)
+            back_want = oracle.bits_to_n_lut(want, n_len)
+            for off in (0, 7):  # aligned: stream kernels; +7: window / shifted twins
+                buf = torch.zeros(n_len + 64, dtype=torch.uint8, device="cuda")
+                d = buf[off : off + n_len]
+                d.copy_(torch.from_numpy(host))
+                bits = cn.n_to_bits_dev(d)
+                assert np.array_equal(bits.cpu().numpy().view(np.uint64), want), (xs, n_len, off)
+                obuf = torch.zeros(n_len + 64, dtype=torch.uint8, device="cuda")
+                cn.bits_to_n_dev(bits, n_len, out=obuf[off : off + n_len])
+                assert np.array_equal(obuf[off : off + n_len].cpu().numpy(), back_want), (xs, n_len, off)
+            f_bits, f_back = cn.round_trip_dev(buf[:n_len].copy_(torch.from_numpy(host)))
+            assert np.array_equal(f_bits.cpu().numpy().view(np.uint64), want) and np.array_equal(f_back.cpu().numpy(), back_want), (xs, n_len)
+        n5 = oracle.fill_random_acgtn(3456 * ((8 << xs) + 3) + 100, 60 + xs)
+        w5 = oracle.n_to_bits2_lut(n5)
+        d5 = torch.from_numpy(n5).cuda()
+        b5 = cn.n_to_bits2_dev(d5)
+        assert np.array_equal(b5.cpu().numpy().view(np.uint64), w5), xs
+        assert np.array_equal(cn.bits_to_n2_dev(b5, n5.size).cpu().numpy(), oracle.bits_to_n2_lut(w5, n5.size)), xs
+    finally:
+        devutil.set_tuning("xcd_shift", -1)
+        devutil.set_tuning("small_nt", saved_small)
+    assert devutil.get_tuning("xcd_shift") in (0, 1, 2, 3)  # back to the device's own answer (8 XCDs -> 3 on an MI355X in SPX mode)
