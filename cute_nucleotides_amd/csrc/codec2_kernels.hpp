@@ -21,13 +21,15 @@
 //     write-through non-temporal (sc0|sc1|nt) stores for both (for encode sc1 alone
 //     is as fast, but leaves the packed buffer in a state that slows the decode that
 //     follows by 1.3 %);
-//   * letting each XCD (block b runs on XCD b%8) take its READ stream in whole 4-KiB pieces --
-//     two 2-KiB ASCII tiles per turn for encode, four 4-KiB output tiles (= 4 KiB of packed
-//     words) per turn for decode -- is worth 1-3 %; other group sizes lose.  What the maps that
-//     win have in common: the eight XCDs read eight CONSECUTIVE pages at a time, each XCD whole
-//     pages, always of the same residue class mod 8 (bench/tune_lab10.hip; the reductions in
-//     packed_ops_kernels.hpp get the same property from vec_offset).  Class affinity without the
-//     consecutive order loses (tried on the 5-letter encoder);
+//   * which XCD touches which 4 KiB (block b is observed to run on XCD b % X): DECODE is 1.5-3 % faster when each XCD
+//     takes its READ stream in whole 4-KiB pieces -- four 4-KiB output tiles (= 4 KiB of packed words) per turn; other
+//     group sizes lose, and what the maps that win have in common is that the XCDs read CONSECUTIVE pages at a time, each
+//     XCD whole pages, always of the same residue class (bench/tune_lab10.hip; the reductions in packed_ops_kernels.hpp
+//     get the same property from vec_offset).  ENCODE shipped with the analogous pair map (two 2-KiB ASCII tiles per
+//     turn) through rounds 1-2; under the residency cap and the store policy adopted AFTER it, plain dispatch order is
+//     0.2-0.9 % faster in encode -> decode steps on five boxes out of five (round 3, bench/xcd_shift_ab.py,
+//     profiles/r03_ab_step_encode_plain_order.log), so encode's default has no map; the pair map is variant 17.  Class
+//     affinity without the consecutive order loses (tried on the 5-letter encoder);
 //   * capping residency at ~24 waves per CU (dummy LDS) is worth another 2-3 %.
 // Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
 // per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)

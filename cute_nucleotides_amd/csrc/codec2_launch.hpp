@@ -74,12 +74,12 @@ inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (chip_info().lds_per_cu
 
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
-    {"stream B=64 U=2 xcd-pairs ld=nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 0: default
+    {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 0: default (round 3; rounds 1-2: variant 17)
     {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16, 256, 0},              // 1
     {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16, 512, 0},          // 2
     {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16, 256, 0},               // 3: the first shape tried
     {"lds B=256 U=4 ld=nt st=sc1", 256 * 4 * 16, 256, 0},                 // 4: LDS-widened stores
-    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16, 64, 0},                // 5: as 0 without the XCD pairing
+    {"stream B=64 U=2 ld=nt st=sc1", 64 * 2 * 16, 64, 0},                // 5: plain order, write-through-only stores, no residency cap
     {"stream B=128 U=2 ld=nt st=sc1", 128 * 2 * 16, 128, 0},              // 6
     {"stream B=64 U=2 xcd-quads ld=nt st=sc1", 64 * 2 * 16, 64, 0},      // 7
     {"stream B=256 U=4 plain", 256 * 4 * 16, 256, 0},                     // 8: no cache-policy bits at all
@@ -92,6 +92,15 @@ constexpr VariantDesc kEncodeVariants[] = {
     {"stream B=64 U=2 xcd-pairs ld=sc1|nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 14
     {"stream B=64 U=2 xcd-pairs ld=sc1 st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},     // 15
     {"stream B=64 U=2 xcd-pairs ld=sc0|sc1|nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 16
+    // round 3, from the xcd_shift A/B (bench/xcd_shift_ab.py): the policies and cap of rounds 1-2's default WITHOUT the XCD
+    // pairing is a combination the ladder never measured (the pairing was adopted before the cap and the store policy
+    // were) -- and in encode -> decode steps it is 0.2-0.9 % FASTER on five boxes out of five
+    // (profiles/r03_ab_step_encode_plain_order.log): it became variant 0, the pairing moved here
+    {"stream B=64 U=2 xcd-pairs ld=nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 17: the default of rounds 1-2
+    {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 22 wg/CU", 64 * 2 * 16, 64, 22},  // 18
+    {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 24 wg/CU", 64 * 2 * 16, 64, 24},  // 19
+    {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 26 wg/CU", 64 * 2 * 16, 64, 26},  // 20
+    {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 20 wg/CU", 64 * 2 * 16, 64, 20},  // 21
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -136,7 +145,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
 #define CNT_ENC_STREAM(B, U, C, L, S) \
     hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     switch (variant) {
-        case 0: CNT_ENC_STREAM(64, 2, 2, kNT, kSC0 | kSC1 | kNT); break;
+        case 0: CNT_ENC_STREAM(64, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
         case 1: CNT_ENC_STREAM(256, 1, 1, kNT, kSC1); break;
         case 2: CNT_ENC_STREAM(512, 1, 1, kSC0 | kNT, kSC1); break;
         case 3: CNT_ENC_STREAM(256, 4, 1, kNT, kNT); break;
@@ -153,6 +162,8 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
         case 14: CNT_ENC_STREAM(64, 2, 2, kSC1 | kNT, kSC0 | kSC1 | kNT); break;
         case 15: CNT_ENC_STREAM(64, 2, 2, kSC1, kSC0 | kSC1 | kNT); break;
         case 16: CNT_ENC_STREAM(64, 2, 2, kSC0 | kSC1 | kNT, kSC0 | kSC1 | kNT); break;
+        case 17: CNT_ENC_STREAM(64, 2, 2, kNT, kSC0 | kSC1 | kNT); break;
+        case 18: case 19: case 20: case 21: CNT_ENC_STREAM(64, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
         default: return 1;
     }
     }
@@ -173,7 +184,7 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         e.groups = first + n_tiles == total_tiles ? edge_groups(encode_edge_items(e), 64, n_tiles) : 0u;
-        hipLaunchKernelGGL((n_to_bits_window<2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+        hipLaunchKernelGGL((n_to_bits_window<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e);
     }
 }

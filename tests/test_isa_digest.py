@@ -48,13 +48,13 @@ def test_every_shipped_kernel_is_lean(isa):
 
 def test_2bit_codec_instruction_selection(isa):
     isa_digest, found = isa
-    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_stream<64, 2, 2, 2, 19, false>")
+    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_stream<64, 2, 1, 2, 19, false>")
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
     assert t["counts"]["buffer_load_dwordx4"] == 2 and t["counts"]["buffer_store_dword"] == 2
     assert "s_and_saveexec_b64" not in t["counts"] and "v_readfirstlane_b32" not in t["counts"]  # nothing divergent in front of the stores
     assert t["counts"]["v_mul_lo_u32"] == 8  # y*0x41041: the reference's n_to_bits_mul identity, found by the compiler
     assert m["group_segment_fixed_size"] == 0 and t["instructions"] <= 90
-    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_window<2, 2, 19, false>")
+    t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_window<1, 2, 19, false>")
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["v_alignbit_b32"] == 2
     assert t["counts"]["buffer_load_dwordx4"] == 3 and "s_and_saveexec_b64" not in t["counts"]
     for name in ("void cnt::bits_to_n_stream<128, 2, 4, 0, 19>", "void cnt::bits_to_n_shifted<128, 2, 4, 0, 19>"):
