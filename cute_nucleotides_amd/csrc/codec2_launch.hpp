@@ -101,6 +101,13 @@ constexpr VariantDesc kEncodeVariants[] = {
     {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 24 wg/CU", 64 * 2 * 16, 64, 24},  // 19
     {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 26 wg/CU", 64 * 2 * 16, 64, 26},  // 20
     {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 20 wg/CU", 64 * 2 * 16, 64, 20},  // 21
+    // the policies once more, now around the plain-order default
+    {"stream B=64 U=2 plain order ld=plain st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},   // 22
+    {"stream B=64 U=2 plain order ld=sc1|nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 23
+    {"stream B=64 U=2 plain order ld=nt st=sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},          // 24
+    {"stream B=64 U=2 plain order ld=nt st=sc1, 23 wg/CU", 64 * 2 * 16, 64, 23},             // 25
+    {"stream B=128 U=2 plain order ld=nt st=sc0|sc1|nt, 11 wg/CU", 128 * 2 * 16, 128, 11},   // 26
+    {"stream B=64 U=4 plain order ld=nt st=sc0|sc1|nt, 12 wg/CU", 64 * 4 * 16, 64, 12},      // 27
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -164,6 +171,12 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
         case 16: CNT_ENC_STREAM(64, 2, 2, kSC0 | kSC1 | kNT, kSC0 | kSC1 | kNT); break;
         case 17: CNT_ENC_STREAM(64, 2, 2, kNT, kSC0 | kSC1 | kNT); break;
         case 18: case 19: case 20: case 21: CNT_ENC_STREAM(64, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
+        case 22: CNT_ENC_STREAM(64, 2, 1, 0, kSC0 | kSC1 | kNT); break;
+        case 23: CNT_ENC_STREAM(64, 2, 1, kSC1 | kNT, kSC0 | kSC1 | kNT); break;
+        case 24: CNT_ENC_STREAM(64, 2, 1, kNT, kSC1 | kNT); break;
+        case 25: CNT_ENC_STREAM(64, 2, 1, kNT, kSC1); break;
+        case 26: CNT_ENC_STREAM(128, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
+        case 27: CNT_ENC_STREAM(64, 4, 1, kNT, kSC0 | kSC1 | kNT); break;
         default: return 1;
     }
     }
