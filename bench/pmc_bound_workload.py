@@ -28,7 +28,7 @@ P = ctypes.CDLL(os.path.join(ROOT, "bench", "libcnt_probes.so"))
 P.probe_shipped.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(a.reps):
-    for kind in (0, 4, 1, 2, 3):
+    for kind in (0, 4, 1, 2, 3, 11, 12, 14, 21, 24):  # 1x: the 1:4 / 4:1 streams with the codec's arithmetic applied x times
         assert P.probe_shipped(kind, d_in.data_ptr(), d_out.data_ptr(), n, s) == 0
     cn.n_to_bits_dev(d_in, out=d_packed)
     cn.bits_to_n_dev(d_packed, n, out=d_out)
