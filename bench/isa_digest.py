@@ -25,8 +25,8 @@ DIGEST = os.path.join(ROOT, "profiles", "r03_isa_digest.txt")
 SHIPPED = [
     ("encode", "void cnt::n_to_bits_stream<64, 2, 1, 2, 19, false>"),
     ("encode, any input phase", "void cnt::n_to_bits_window<1, 2, 19, false>"),
-    ("decode", "void cnt::bits_to_n_stream<128, 2, 4, 0, 19>"),
-    ("decode, any output phase", "void cnt::bits_to_n_shifted<128, 2, 4, 0, 19>"),
+    ("decode", "void cnt::bits_to_n_stream<64, 4, 4, 0, 19>"),
+    ("decode, any output phase", "void cnt::bits_to_n_shifted<64, 4, 4, 0, 19>"),
     ("fused round trip", "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>"),
     ("5-letter encode", "void cnt::n_to_bits2_wave<1, 2, 2, 16, false, 1>"),
     ("5-letter decode", "void cnt::bits_to_n2_wave<1, 2, 0, 19, 4>"),

@@ -42,10 +42,10 @@ def main():
                 durations[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     want = [("read_only probe (1024 thr x 1 load, nt)", "shipped::k_read<", n, 0), ("write_only probe (256 thr x 1 store)", "shipped::k_write<", 0, n),
             ("copy 1:1 probe", "shipped::k_copy<", n, n), ("read4:write1 probe (encode's shape, no arithmetic)", "shipped::k_r4w1<64", n, n // 4),
-            ("read1:write4 probe (decode's shape, no arithmetic)", "shipped::k_r1w4<128", n // 4, n),
-            ("read1:write4 probe + decode arithmetic x1", "shipped::k_r1w4_arith<128, 2, 4, 0, 19, 1>", n // 4, n),
-            ("read1:write4 probe + decode arithmetic x2", "shipped::k_r1w4_arith<128, 2, 4, 0, 19, 2>", n // 4, n),
-            ("read1:write4 probe + decode arithmetic x4", "shipped::k_r1w4_arith<128, 2, 4, 0, 19, 4>", n // 4, n),
+            ("read1:write4 probe (decode's shape, no arithmetic)", "shipped::k_r1w4<", n // 4, n),
+            ("read1:write4 probe + decode arithmetic x1", "shipped::k_r1w4_arith<64, 4, 4, 0, 19, 1>", n // 4, n),
+            ("read1:write4 probe + decode arithmetic x2", "shipped::k_r1w4_arith<64, 4, 4, 0, 19, 2>", n // 4, n),
+            ("read1:write4 probe + decode arithmetic x4", "shipped::k_r1w4_arith<64, 4, 4, 0, 19, 4>", n // 4, n),
             ("read4:write1 probe + encode arithmetic x1", "shipped::k_r4w1_arith<64, 2, 1, 2, 19, 1>", n, n // 4),
             ("read4:write1 probe + encode arithmetic x4", "shipped::k_r4w1_arith<64, 2, 1, 2, 19, 4>", n, n // 4),
             ("n_to_bits_stream (encode)", "cnt::n_to_bits_stream<", n, n // 4), ("bits_to_n_stream (decode)", "cnt::bits_to_n_stream<", n // 4, n),

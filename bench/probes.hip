@@ -244,10 +244,10 @@ extern "C" int probe_shipped(int kind, const void* a, void* b, size_t bytes, voi
         case 0: { const uint32_t t = (uint32_t)(bytes / (1024 * 16)); hipLaunchKernelGGL((shipped::k_read<1024, 1, kNT>), dim3(t), dim3(1024), 0, s, pa, pb, t); break; }
         case 1: { const uint32_t t = (uint32_t)(bytes / (256 * 16)); hipLaunchKernelGGL((shipped::k_copy<256, 1, 1, kNT, kAll>), dim3(t), dim3(256), 0, s, pa, pb, t, xs); break; }
         case 2: { const uint32_t t = (uint32_t)(bytes / (64 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r4w1<64, 2, 1, kNT, kAll>), dim3(t), dim3(64), lds_for_cap(23), s, pa, pb, t, xs); break; }
-        case 3: { const uint32_t t = (uint32_t)(bytes / (128 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r1w4<128, 2, 4, 0, kAll>), dim3(t), dim3(128), lds_for_cap(13), s, pa, pb, t, xs); break; }
+        case 3: { const uint32_t t = (uint32_t)(bytes / (64 * 4 * 16)); hipLaunchKernelGGL((shipped::k_r1w4<64, 4, 4, 0, kAll>), dim3(t), dim3(64), lds_for_cap(14), s, pa, pb, t, xs); break; }
         case 4: { const uint32_t t = (uint32_t)(bytes / (256 * 16)); hipLaunchKernelGGL((shipped::k_write<256, 1, kAll>), dim3(t), dim3(256), 0, s, pb, t); break; }
         // kinds 10 + R / 20 + R: the 1:4 / 4:1 shapes with the codec's own arithmetic applied R = 1, 2, 4 times (dependent chain)
-#define CNT_P14(R) { const uint32_t t = (uint32_t)(bytes / (128 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r1w4_arith<128, 2, 4, 0, kAll, R>), dim3(t), dim3(128), lds_for_cap(13), s, pa, pb, t, xs); break; }
+#define CNT_P14(R) { const uint32_t t = (uint32_t)(bytes / (64 * 4 * 16)); hipLaunchKernelGGL((shipped::k_r1w4_arith<64, 4, 4, 0, kAll, R>), dim3(t), dim3(64), lds_for_cap(14), s, pa, pb, t, xs); break; }
 #define CNT_P41(R) { const uint32_t t = (uint32_t)(bytes / (64 * 2 * 16)); hipLaunchKernelGGL((shipped::k_r4w1_arith<64, 2, 1, kNT, kAll, R>), dim3(t), dim3(64), lds_for_cap(23), s, pa, pb, t, xs); break; }
         case 11: CNT_P14(1) case 12: CNT_P14(2) case 14: CNT_P14(4) case 18: CNT_P14(8)
         case 21: CNT_P41(1) case 22: CNT_P41(2) case 24: CNT_P41(4) case 28: CNT_P41(8)

@@ -236,7 +236,7 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
 
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
-    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},  // 0: default
+    {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},  // 0: default (round 3; rounds 1-2: variant 35)
     {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16, 256, 0},        // 1
     {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16, 64, 0},  // 2
     {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16, 256, 0},                   // 3: the first shape tried
@@ -272,6 +272,25 @@ constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=128 U=2 xcd-quads ld=plain st=sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},        // 29
     {"stream B=128 U=2 xcd-quads ld=plain st=sc0|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},        // 30
     {"stream B=128 U=2 xcd-quads ld=plain st=sc1, 13 wg/CU", 128 * 2 * 16, 128, 13},           // 31
+    // shapes once more, with the 4-instruction decoder: the stream is in-flight-limited (profiles/r03_bound_counters.json),
+    // so: more requests per wave instead of more waves?  Yes: ONE wave per 4-KiB tile with four 4-B loads per lane, still
+    // four tiles per XCD turn, 14 workgroups per CU is 0.9-1.6 % faster than two waves x two loads under 13 in encode ->
+    // decode steps on six boxes out of six (profiles/r03_ab_step_decode_one_wave_tiles.log): it became variant 0, the old
+    // default moved to 35 (the fused kernel's own sweep had found the same shape in round 2)
+    {"stream B=128 U=4 xcd-pairs ld=plain st=sc0|sc1|nt, 7 wg/CU", 128 * 4 * 16, 128, 7},      // 32: 8-KiB tiles, 2 per XCD turn
+    {"stream B=128 U=4 xcd-pairs ld=plain st=sc0|sc1|nt, 6 wg/CU", 128 * 4 * 16, 128, 6},      // 33
+    {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 13 wg/CU", 64 * 4 * 16, 64, 13},       // 34: one wave per 4-KiB tile
+    {"stream B=128 U=2 xcd-quads ld=plain st=sc0|sc1|nt, 13 wg/CU", 128 * 2 * 16, 128, 13},    // 35: the default of rounds 1-2
+    {"stream B=256 U=2 xcd-pairs ld=plain st=sc0|sc1|nt, 6 wg/CU", 256 * 2 * 16, 256, 6},      // 36
+    {"stream B=256 U=2 xcd-pairs ld=plain st=sc0|sc1|nt, 7 wg/CU", 256 * 2 * 16, 256, 7},      // 37
+    {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 12 wg/CU", 64 * 4 * 16, 64, 12},       // 38
+    {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 15 wg/CU", 64 * 4 * 16, 64, 15},       // 39
+    {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 16 wg/CU", 64 * 4 * 16, 64, 16},       // 40
+    {"stream B=64 U=4 xcd-pairs ld=plain st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},       // 41
+    {"stream B=64 U=4 plain order ld=plain st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},     // 42
+    {"stream B=64 U=8 xcd-pairs ld=plain st=sc0|sc1|nt, 7 wg/CU", 64 * 8 * 16, 64, 7},         // 43
+    {"stream B=64 U=4 xcd-quads ld=sc1 st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},         // 44
+    {"stream B=64 U=4 xcd-quads ld=plain st=sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},           // 45
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -297,7 +316,7 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
 #define CNT_DEC_STREAM(B, U, C, L, S) \
     hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     switch (variant) {
-        case 0: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
+        case 0: CNT_DEC_STREAM(64, 4, 4, 0, kAll); break;
         case 1: CNT_DEC_STREAM(256, 2, 1, 0, kAll); break;
         case 2: CNT_DEC_STREAM(64, 2, 2, 0, kAll); break;
         case 3: CNT_DEC_STREAM(256, 2, 1, kNT, kNT); break;
@@ -323,6 +342,15 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 29: CNT_DEC_STREAM(128, 2, 4, 0, kSC1 | kNT); break;
         case 30: CNT_DEC_STREAM(128, 2, 4, 0, kSC0 | kNT); break;
         case 31: CNT_DEC_STREAM(128, 2, 4, 0, kSC1); break;
+        case 32: case 33: CNT_DEC_STREAM(128, 4, 2, 0, kAll); break;
+        case 35: CNT_DEC_STREAM(128, 2, 4, 0, kAll); break;
+        case 34: case 38: case 39: case 40: CNT_DEC_STREAM(64, 4, 4, 0, kAll); break;
+        case 41: CNT_DEC_STREAM(64, 4, 2, 0, kAll); break;
+        case 42: CNT_DEC_STREAM(64, 4, 1, 0, kAll); break;
+        case 43: CNT_DEC_STREAM(64, 8, 2, 0, kAll); break;
+        case 44: CNT_DEC_STREAM(64, 4, 4, kSC1, kAll); break;
+        case 45: CNT_DEC_STREAM(64, 4, 4, 0, kSC1 | kNT); break;
+        case 36: case 37: CNT_DEC_STREAM(256, 2, 2, 0, kAll); break;
         case 21: CNT_DEC_STREAM(128, 2, 4, kNT, kAll); break;
         default: return 1;
     }
@@ -333,16 +361,16 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
 
 // The any-alignment companion of decode variant 0: `in` = the dword holding the first
 // nucleotide, `sh` = 2 * (its index among that dword's 16).
-constexpr uint32_t kShiftedDecodeTile = 128 * 2 * 16;
+constexpr uint32_t kShiftedDecodeTile = 64 * 4 * 16;
 inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, DecodeEdges e, hipStream_t s) {
-    const uint64_t per_launch = max_tiles_per_launch(128);
-    const uint32_t lds = lds_for_cap(13);
+    const uint64_t per_launch = max_tiles_per_launch(64);
+    const uint32_t lds = lds_for_cap(14);
     const uint32_t xs = xcd_shift();
     e.tail_lo = e.head + total_tiles * kShiftedDecodeTile;
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
-        e.groups = first + n_tiles == total_tiles ? edge_groups(decode_edge_items(e), 128, n_tiles) : 0u;
-        hipLaunchKernelGGL((bits_to_n_shifted<128, 2, 4, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(128), lds, s,
+        e.groups = first + n_tiles == total_tiles ? edge_groups(decode_edge_items(e), 64, n_tiles) : 0u;
+        hipLaunchKernelGGL((bits_to_n_shifted<64, 4, 4, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, (uint32_t)n_tiles, sh, xs, e);
     }
 }

@@ -15,7 +15,7 @@ VALID = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
 SIZES = [1, 3, 4, 31, 32, 33, 63, 64, 65, 255, 256, 4095, 4096, 4097, 16383, 16384, 16385,
          32768 + 5, 65536, 100003, (1 << 20), (1 << 20) + 13, (1 << 22) + 16384 + 31]
 
-N_ENC_VARIANTS, N_DEC_VARIANTS = 28, 32  # kEncodeVariants / kDecodeVariants in csrc/codec2_launch.hpp (checked below)
+N_ENC_VARIANTS, N_DEC_VARIANTS = 28, 46  # kEncodeVariants / kDecodeVariants in csrc/codec2_launch.hpp (checked below)
 
 
 @pytest.fixture(scope="module")

@@ -57,10 +57,10 @@ def test_2bit_codec_instruction_selection(isa):
     t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_window<1, 2, 19, false>")
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["v_alignbit_b32"] == 2
     assert t["counts"]["buffer_load_dwordx4"] == 3 and "s_and_saveexec_b64" not in t["counts"]
-    for name in ("void cnt::bits_to_n_stream<128, 2, 4, 0, 19>", "void cnt::bits_to_n_shifted<128, 2, 4, 0, 19>"):
+    for name in ("void cnt::bits_to_n_stream<64, 4, 4, 0, 19>", "void cnt::bits_to_n_shifted<64, 4, 4, 0, 19>"):
         t, w, m = _tile(isa_digest, found, name)
-        assert t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["buffer_store_dwordx4"] == 2
-        assert t["counts"]["v_perm_b32"] == 8  # the 4-entry "ACTG" table, one per packed byte
+        assert t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["buffer_store_dwordx4"] == 4
+        assert t["counts"]["v_perm_b32"] == 16  # the 4-entry "ACTG" table, one per packed byte (four packed dwords per lane)
         assert "s_and_saveexec_b64" not in t["counts"] and m["next_free_vgpr"] <= 24
     t, w, m = _tile(isa_digest, found, "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>")
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
