@@ -21,6 +21,7 @@ ap.add_argument("--dec", default="0,9")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--five", action="store_true", help="the 5-letter codec (tuning keys encode2 / decode2)")
+ap.add_argument("--dist", action="store_true", help="also print every decode launch's time, sorted (is a median hiding two modes?)")
 a = ap.parse_args()
 n = 1 << a.log2_nt
 if a.five:
@@ -36,7 +37,7 @@ d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
 encs = [int(x) for x in a.enc.split(",")]
 decs = [int(x) for x in a.dec.split(",")]
 pairs = [(e, d) for e in encs for d in decs]
-res = {p: {"enc": [], "dec": [], "step": []} for p in pairs}
+res = {p: {"enc": [], "dec": [], "step": [], "dec_each": [], "enc_each": []} for p in pairs}
 names_e, names_d = dict(devutil.variants(K_ENC)), dict(devutil.variants(K_DEC))
 for r in range(a.rounds + 1):
     for p in pairs:
@@ -57,9 +58,15 @@ for r in range(a.rounds + 1):
         res[p]["enc"].append(sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps)
         res[p]["dec"].append(sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps)
         res[p]["step"].append(ev[0][0].elapsed_time(ev[-1][2]) / a.steps)
+        res[p]["enc_each"] += [e[0].elapsed_time(e[1]) for e in ev]
+        res[p]["dec_each"] += [e[1].elapsed_time(e[2]) for e in ev]
 devutil.set_tuning(K_ENC, 0)
 devutil.set_tuning(K_DEC, 0)
 for p in sorted(pairs, key=lambda p: statistics.median(res[p]["step"])):
     e, d, s = (statistics.median(res[p][k]) for k in ("enc", "dec", "step"))
     print("enc v%-2d dec v%-2d  step %.4f ms  enc %.4f ms = %6.1f GB/s  dec %.4f ms = %6.1f GB/s   | %s | %s" % (
         p[0], p[1], s, e, bpn * n / e / 1e6, d, bpn * n / d / 1e6, names_e[p[0]], names_d[p[1]]))
+    if a.dist:
+        for k in ("enc_each", "dec_each"):
+            v = sorted(res[p][k])
+            print("    %s mean %.4f  deciles %s" % (k[:3], statistics.mean(v), " ".join("%.3f" % v[min(len(v) - 1, len(v) * q // 10)] for q in range(11))))
