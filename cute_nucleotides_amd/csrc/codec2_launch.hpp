@@ -117,7 +117,17 @@ inline unsigned grid_of(uint64_t n_tiles) { return (unsigned)(n_tiles > 0x7FFFFF
 // ("invalid configuration argument"): 2^36 nt in 2 KiB tiles is 2^25 workgroups of
 // 64 = 2^31 threads.  Large buffers are therefore cut into several launches of at
 // most this many tiles (a multiple of 64, so every XCD-group permutation stays whole).
-inline uint64_t max_tiles_per_launch(int block) { return ((0x7FFFFFFFull / (uint64_t)block) / 64) * 64; }
+// The tuning key "launch_tiles" lowers the limit (a multiple of 64; 0 = the hardware's) so that the tests can walk every
+// launcher's several-launch loop -- and the rule that the edges ride in the LAST launch only -- at sizes of a few MiB.
+inline std::atomic<int>& launch_tiles_override() {
+    static std::atomic<int> v{0};
+    return v;
+}
+inline uint64_t max_tiles_per_launch(int block) {
+    const uint64_t hw = ((0x7FFFFFFFull / (uint64_t)block) / 64) * 64;
+    const int o = launch_tiles_override().load(std::memory_order_relaxed);
+    return o > 0 && (uint64_t)o < hw ? (uint64_t)o : hw;
+}
 // how many of a launch's last workgroups share the edge items (one item per thread when there are enough tiles; the
 // edge bodies are strided loops, so any count >= 1 covers all items)
 constexpr unsigned kMaxEdgeGroups = 64;

@@ -361,6 +361,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "small_nt")) {
         if (value < 0) return CNT_EINVAL;
         g_small_nt.store(value);
+    } else if (!strcmp(key, "launch_tiles")) {
+        if (value < 0 || value % 64) return CNT_EINVAL;  // whole XCD-group permutations per launch
+        launch_tiles_override().store(value);
     } else {
         return CNT_EINVAL;
     }
@@ -375,6 +378,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
     else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
     else if (!strcmp(key, "xcd_shift")) *value = (int)xcd_shift();
+    else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
     else if (!strcmp(key, "round_trip_shape")) *value = g_round_trip_shape.load();

@@ -236,6 +236,8 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
  * tiles read their pages XCD-interleaved when "reduce_xi" is 1.
  * "xcd_shift": log2 of the XCD count the block -> tile maps assume (-1 = ask the device, the default; get returns the
  * value in effect) -- the maps are bijections for every value, only speed depends on it.
+ * "launch_tiles": most tiles one kernel launch may take (a multiple of 64; 0 = the hardware's limit of 2^31-1 threads,
+ * the default) -- test support: lets a few MiB walk the several-launch loops that otherwise start at 2^36 nt.
  * cnt_tuning_name returns the variant's description (NULL when out of range).
  * CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);
