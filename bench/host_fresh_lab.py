@@ -3,7 +3,9 @@
 benches/bench_n_to_bits.rs:6-7) against reused outputs, under the library's environment knobs -- one child process
 per setting (the knobs are read once per process).  (profiles/r03_host_fresh_lab.jsonl and r03_host_pipeline_slots.jsonl
 were produced by an earlier version of this script, which also had rows for the fault-in helper team that round 3 built,
-measured and removed: CNT_HOST_PREFAULT / CNT_HOST_PREFAULT_THREADS in their `env` columns.)
+measured and removed: CNT_HOST_PREFAULT / CNT_HOST_PREFAULT_THREADS in their `env` columns; r03_host_copy_blocks.jsonl and
+r03_host_numa_placement.jsonl by versions with lab-only knobs of the copy pool, see their first lines.)  CNT_LAB_PIN = gpu | other
+confines the CHILD (caller, its data and the library's helpers) to the CPUs of the GPU's NUMA node / of another node.
 
     python bench/host_fresh_lab.py [--log2-nt 30] [--reps 8]
 
@@ -22,16 +24,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SETTINGS = [
-    ("default (huge-page advice, 3 pipeline slots, 4 copy threads / 8 for copy-outs into fresh pages)", {}),
+    ("default (huge-page advice, 3 pipeline slots, 4 copy threads / 8 into fresh pages), caller wherever the scheduler puts it", {}),
+    ("default, run 2", {}),
+    ("caller and its data on the GPU's NUMA node", {"CNT_LAB_PIN": "gpu"}),
+    ("caller and its data on the other node", {"CNT_LAB_PIN": "other"}),
     ("no huge-page advice (numpy still advises its own allocations)", {"CNT_HOST_HUGEPAGE": "0"}),
     ("2 pipeline slots (rounds 1-2)", {"CNT_HOST_SLOTS": "2"}),
     ("4 pipeline slots", {"CNT_HOST_SLOTS": "4"}),
     ("2 copy threads (4 into fresh pages)", {"CNT_HOST_COPY_THREADS": "2"}),
+    ("6 copy threads (12 into fresh pages)", {"CNT_HOST_COPY_THREADS": "6"}),
     ("8 copy threads (16 into fresh pages)", {"CNT_HOST_COPY_THREADS": "8"}),
 ]
 
 
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin(where):
+    """restrict this process (before any thread exists) to the CPUs of the GPU's NUMA node, or of another node"""
+    import glob
+
+    nodes = {}
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        nodes[int(d.rsplit("node", 1)[1])] = parse_cpulist(open(d + "/cpulist").read())
+    gpu_node = None
+    try:
+        gpu_node = int(open("/sys/bus/pci/devices/%s/numa_node" % os.environ["CNT_LAB_GPU_BDF"]).read())
+    except (OSError, KeyError, ValueError):
+        pass
+    if gpu_node is None or len(nodes) < 2:
+        return {"gpu_node": gpu_node, "nodes": len(nodes), "pinned": None}
+    target = gpu_node if where == "gpu" else sorted(k for k in nodes if k != gpu_node)[-1]
+    os.sched_setaffinity(0, nodes[target] & os.sched_getaffinity(0))
+    return {"gpu_node": gpu_node, "nodes": len(nodes), "pinned": target, "cpus": len(os.sched_getaffinity(0))}
+
+
 def child(log2_nt, reps):
+    pinned = pin(os.environ["CNT_LAB_PIN"]) if os.environ.get("CNT_LAB_PIN") else None
     import numpy as np
 
     from cute_nucleotides_amd import _lib
@@ -87,6 +122,7 @@ def child(log2_nt, reps):
     assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0 and np.array_equal(out, n)
     rows["fresh_over_reused"] = {"n_to_bits_hip": round(rows["n_to_bits_hip fresh"]["ms"] / rows["n_to_bits_hip reused"]["ms"], 3),
                                  "bits_to_n_hip": round(rows["bits_to_n_hip fresh"]["ms"] / rows["bits_to_n_hip reused"]["ms"], 3)}
+    rows["pin"] = pinned
     print(json.dumps(rows))
 
 
@@ -101,6 +137,10 @@ if __name__ == "__main__":
         child(a.log2_nt, a.reps)
         sys.exit(0)
     picked = [SETTINGS[int(i)] for i in a.settings.split(",") if i] or SETTINGS
+    bdf = subprocess.run([sys.executable, "-c", "import torch; p = torch.cuda.get_device_properties(0); print('%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))"],
+                         capture_output=True, text=True).stdout.strip()
+    os.environ["CNT_LAB_GPU_BDF"] = bdf
+    print(json.dumps({"gpu_bdf": bdf}), flush=True)
     for name, env in picked:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--log2-nt", str(a.log2_nt), "--reps", str(a.reps)],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

@@ -37,6 +37,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include "codec2_kernels.hpp"
 #include "codec2_launch.hpp"

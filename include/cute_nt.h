@@ -252,7 +252,8 @@ int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xc
 
 /* ---- environment variables the host tiers read (all optional) -------------------
  *   CNT_HOST_COPY_THREADS        staging-copy threads per calling thread (default 4, 1 = none); copy-outs into outputs
- *                                whose pages do not exist yet (a fresh Vec) use twice as many
+ *                                whose pages do not exist yet (a fresh Vec) use twice as many.  The helpers spin for up
+ *                                to 150 us after a copy before they go to sleep, i.e. for the length of a pipelined call
  *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 3, 2..4)
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
