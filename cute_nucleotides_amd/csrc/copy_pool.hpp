@@ -1,0 +1,160 @@
+// copy_pool.hpp -- the host tier's staging-copy team.  Plain C++17, no HIP: included by cute_nt.hip (inside its anonymous
+// namespace, through shim_host_ctx.inc) and, on its own, by tests/copy_pool_stress.cpp, which hammers it under
+// ThreadSanitizer on the CPU box.
+#pragma once
+// (cute_nt.hip includes every header below at file scope BEFORE it opens its namespace: the lines are no-ops there)
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+// ---- per-thread host-copy helpers ---------------------------------------------------
+// The host tier stages caller memory through pinned buffers (measured on MI355X / PCIe Gen5,
+// profiles/r01_host_tier_lab.log: pageable hipMemcpyAsync runs at 43 GB/s only after the runtime
+// has pinned the caller's pages and at 8-14 GB/s on first touch; explicit staging is 20-25 GB/s
+// with one copying thread and ~40 GB/s with four, cold or warm).  A small team of helper threads per calling
+// thread does the staging copies with it; CNT_HOST_COPY_THREADS (default 4, 1 = no helpers) sizes it.
+class CopyPool {
+   public:
+    ~CopyPool() { stop(); }
+    // Copies INTO FRESH PAGES (the copy-out of a call whose output has never been touched) use the whole pool, every
+    // other copy half of it: each first touch is a page fault, faults parallelise, and 8 threads take a 1-GiB decode into
+    // a fresh buffer from 35 to 27 ms (profiles/r03_host_pipeline_slots.jsonl).
+    //
+    // The team is built for copies that take 50-400 us each, dozens of times per call: a copy is cut into blocks
+    // that the caller and the helpers STEAL from one counter (a helper that wakes up late finds nothing left and costs
+    // nothing), and a helper that has run dry spins on the job generation for kSpinUs before it goes to sleep on the
+    // condition variable -- inside a pipelined call it never sleeps, so a copy starts within a microsecond instead of the
+    // 20-50 us of a condition-variable wake-up (which made 8 threads SLOWER than 4 in the first version of this pool).
+    void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false) {
+        const int all = threads();
+        const int T = fresh_pages ? all : std::max(1, all / 2);  // the pool holds twice the warm-copy team
+        if (bytes < kMinPar || T <= 1) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
+        // blocks are cut on multiples of the block size of the DESTINATION address (the first one is short): with 2-MiB
+        // blocks a huge page of a fresh output is faulted in by ONE thread instead of being fought over by eight
+        const size_t blk = fresh_pages ? kFreshBlock : kWarmBlock;
+        const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
+        const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
+        job_blk_.store(blk, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
+        next_.store(g << 32, std::memory_order_seq_cst);  // from here on nobody can take a block of the previous job
+        job_dst_.store(dst, std::memory_order_relaxed);
+        job_src_.store(src, std::memory_order_relaxed);
+        job_bytes_.store(bytes, std::memory_order_relaxed);
+        job_team_.store(T, std::memory_order_relaxed);
+        gen_.store(g, std::memory_order_seq_cst);
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_work_.notify_all();
+        }
+        work(g, dst, src, bytes, blk);
+        for (unsigned spins = 1; done_.load(std::memory_order_acquire) != nblocks; ++spins) cpu_relax();  // blocks still in other hands: < 30 us
+    }
+    // Sharded tier: worker pools are sized so that the TOTAL over all devices stays bounded
+    // (0 = back to CNT_HOST_COPY_THREADS).  Takes effect at the next copy().
+    void set_limit(int n) {
+        if (n == limit_) return;
+        limit_ = n;
+        if (started_) stop();
+    }
+    int size() const { return started_ ? n_threads_ / 2 : 0; }  // the warm-copy team (what CNT_HOST_COPY_THREADS / the sharded budget count)
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_.store(true, std::memory_order_seq_cst);
+        }
+        cv_work_.notify_all();
+        for (auto& t : workers_) t.join();
+        workers_.clear();
+        stop_.store(false, std::memory_order_relaxed);
+        started_ = false;
+    }
+
+   private:
+    // Block sizes (bench/host_fresh_lab.py, profiles/r03_host_copy_blocks.jsonl): warm copies in 1-MiB blocks -- 256 KiB is as
+    // fast when the copying threads sit on the staging memory's NUMA node and 25 % slower when they do not (30 vs 23.5 ms
+    // per 1-GiB encode); copies into fresh pages in 2-MiB blocks cut on the DESTINATION's 2-MiB grid, so that one thread
+    // faults a transparent huge page in instead of eight fighting over it (1-GiB decode into a fresh buffer 35 -> 24 ms).
+    static constexpr size_t kMinPar = (size_t)512 << 10, kWarmBlock = (size_t)1 << 20, kFreshBlock = (size_t)2 << 20;
+    static constexpr int kSpinUs = 150;
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    int threads() {
+        if (!started_) {
+            started_ = true;
+            int t = 4;
+            if (const char* e = getenv("CNT_HOST_COPY_THREADS")) t = atoi(e);
+            if (limit_ > 0) t = std::min(t, limit_);
+            n_threads_ = 2 * std::max(1, std::min(t, 16));  // warm copies use half of them
+            const uint64_t seen = gen_.load(std::memory_order_relaxed);
+            for (int k = 1; k < n_threads_; ++k) workers_.emplace_back([this, k, seen] { run(k, seen); });
+        }
+        return n_threads_;
+    }
+    // take blocks of job `g` until none is left; the generation in the counter's high half keeps a straggler of an
+    // older job from ever taking (and losing) a block of this one
+    void work(uint64_t g, uint8_t* dst, const uint8_t* src, size_t bytes, size_t blk) {
+        const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
+        const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
+        for (;;) {
+            uint64_t cur = next_.load(std::memory_order_acquire);
+            if ((cur >> 32) != (g & 0xFFFFFFFFull) || (cur & 0xFFFFFFFFull) >= nblocks) return;
+            if (!next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
+            const size_t b = (size_t)(cur & 0xFFFFFFFFull);
+            const size_t lo = b ? b * blk - skew : 0, hi = std::min(bytes, (b + 1) * blk - skew);
+            memcpy(dst + lo, src + lo, hi - lo);
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void run(int k, uint64_t seen) {
+        for (;;) {
+            // wait for a new generation: spin first (the next copy of a pipelined call is microseconds away), then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 1; gen_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed); ++spins) {
+                cpu_relax();
+                if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    sleepers_.fetch_add(1, std::memory_order_seq_cst);
+                    cv_work_.wait(lk, [&] { return stop_.load(std::memory_order_seq_cst) || gen_.load(std::memory_order_seq_cst) != seen; });
+                    sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+                    break;
+                }
+            }
+            if (stop_.load(std::memory_order_seq_cst)) return;
+            const uint64_t g = gen_.load(std::memory_order_acquire);
+            if (g == seen) continue;
+            seen = g;
+            // the job's fields were written before gen_ was: they belong to `g` or to a LATER job, and in the second case
+            // the counter no longer carries `g` and work() returns at once
+            uint8_t* dst = job_dst_.load(std::memory_order_relaxed);
+            const uint8_t* src = job_src_.load(std::memory_order_relaxed);
+            const size_t bytes = job_bytes_.load(std::memory_order_relaxed);
+            if (k >= job_team_.load(std::memory_order_relaxed)) continue;
+            work(g, dst, src, bytes, job_blk_.load(std::memory_order_relaxed));
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_work_;
+    std::vector<std::thread> workers_;
+    std::atomic<uint64_t> gen_{0}, next_{0}, done_{0};
+    std::atomic<uint8_t*> job_dst_{nullptr};
+    std::atomic<const uint8_t*> job_src_{nullptr};
+    std::atomic<size_t> job_bytes_{0}, job_blk_{0};
+    std::atomic<int> job_team_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
+    int n_threads_ = 1, limit_ = 0;
+    bool started_ = false;
+};
