@@ -123,6 +123,22 @@ def child(log2_nt, reps):
     rows["fresh_over_reused"] = {"n_to_bits_hip": round(rows["n_to_bits_hip fresh"]["ms"] / rows["n_to_bits_hip reused"]["ms"], 3),
                                  "bits_to_n_hip": round(rows["bits_to_n_hip fresh"]["ms"] / rows["bits_to_n_hip reused"]["ms"], 3)}
     rows["pin"] = pinned
+    try:  # where did the big mappings of this process land?  (the pinned staging buffers are 3 x 16 MiB + 3 x 4 MiB and 3 x 4 + 3 x 16)
+        big = []
+        for line in open("/proc/self/numa_maps"):
+            f = line.split()
+            pages = {k: int(v) for k, v in (x.split("=") for x in f[2:] if "=" in x and x.split("=")[0] in ("N0", "N1", "N2", "N3"))}
+            if 1024 <= sum(pages.values()) <= 8192 and "heap" not in line and "stack" not in line:
+                big.append((sum(pages.values()), pages, [x for x in f[2:] if x.startswith(("file=", "anon", "huge", "kernelpagesize"))][:2]))
+        rows["mappings_4_to_32MiB"] = big[:40]
+    except OSError:
+        pass
+    try:
+        cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else ctypes.CDLL(None).sched_getcpu()
+        node = [d for d in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu) if d.startswith("node")]
+        rows["caller_cpu_at_end"] = {"cpu": cpu, "node": node[0] if node else None}
+    except OSError:
+        pass
     print(json.dumps(rows))
 
 
@@ -132,6 +148,7 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--settings", default="", help="comma list of indices into SETTINGS (default: all)")
+    ap.add_argument("--repeat", type=int, default=1, help="run the picked settings this many times (how often does a process land badly?)")
     a = ap.parse_args()
     if a.child:
         child(a.log2_nt, a.reps)
@@ -141,7 +158,7 @@ if __name__ == "__main__":
                          capture_output=True, text=True).stdout.strip()
     os.environ["CNT_LAB_GPU_BDF"] = bdf
     print(json.dumps({"gpu_bdf": bdf}), flush=True)
-    for name, env in picked:
+    for name, env in picked * a.repeat:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--log2-nt", str(a.log2_nt), "--reps", str(a.reps)],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
