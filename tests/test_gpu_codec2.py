@@ -885,3 +885,36 @@ def test_tile_maps_are_bijections_for_any_xcd_count(cn, oracle, torch_cuda, xs):
         devutil.set_tuning("xcd_shift", -1)
         devutil.set_tuning("small_nt", saved_small)
     assert devutil.get_tuning("xcd_shift") in (0, 1, 2, 3)  # back to the device's own answer (8 XCDs -> 3 on an MI355X in SPX mode)
+
+
+def test_host_tier_outputs_at_odd_offsets_in_fresh_and_warm_pages(cn, oracle):
+    """The copy team cuts a copy-out into blocks on the DESTINATION's 1-MiB (warm) or 2-MiB (fresh pages) grid: outputs
+    that start anywhere inside a page, in mappings whose pages do not exist yet (the first call) and in the same
+    mappings once they do (the second call), with guard bytes on both sides."""
+    import ctypes
+
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    n_len = (48 << 20) + 12345  # three 16-Mi-nt chunks and a ragged end; decode's output is > 8 MiB: "fresh" is detected
+    n = oracle.fill_random_acgt(n_len, 77)
+    words = (n_len + 31) // 32
+    want = oracle.n_to_bits_movemask(n)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for off in (0, 8, 4096 + 24, (2 << 20) - 8, (1 << 20) + 40):
+        obuf = np.empty(words * 8 + (4 << 20), dtype=np.uint8)  # a fresh mapping: nothing below touches it before the call
+        dbuf = np.empty(n_len + (4 << 20), dtype=np.uint8)
+        for attempt in ("fresh", "warm"):
+            out = obuf[off : off + words * 8].view(np.uint64)
+            assert L.cnt_n_to_bits(p(n), n_len, p(out), words) == 0
+            assert np.array_equal(out, want), (off, attempt)
+            back = dbuf[off + 3 : off + 3 + n_len]
+            assert L.cnt_bits_to_n(p(out), words, n_len, p(back)) == 0
+            assert np.array_equal(back, n), (off, attempt)
+            if attempt == "fresh":  # guards go in once the pages exist; the warm pass must leave them alone
+                obuf[:off] = 0xA5
+                obuf[off + words * 8 :] = 0xA5
+                dbuf[: off + 3] = 0x5A
+                dbuf[off + 3 + n_len :] = 0x5A
+        assert (obuf[:off] == 0xA5).all() and (obuf[off + words * 8 :] == 0xA5).all(), off
+        assert (dbuf[: off + 3] == 0x5A).all() and (dbuf[off + 3 + n_len :] == 0x5A).all(), off
