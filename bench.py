@@ -786,13 +786,25 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        try:
-            if backend == "nccl":
+        def bring_up(name):
+            if name == "nccl":
                 dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
             else:
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-                dist.init_process_group(backend=backend)
+                dist.init_process_group(backend=name)
             dist.barrier()  # first collective: lazy connection chatter happens here, not later
+
+        try:
+            try:
+                bring_up(backend)
+            except Exception as exc:  # the control plane must not be what stops a scaling run: try the other backend once
+                other = "nccl" if backend != "nccl" else "gloo"
+                print("bench.py: process group over %s failed (%s); trying %s" % (backend, str(exc)[:200], other), file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = other
+                red_dev = dev if backend == "nccl" else torch.device("cpu")
+                bring_up(backend)
         finally:
             sys.stdout.flush()
             if rank == 0:
