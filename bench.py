@@ -486,7 +486,54 @@ def measure_host_tier(seed):
                 row[name + " us"] = round(dt / reps * 1e6, 2)
         assert np.array_equal(back, n)
         rows["2^%d" % log2] = row
+    rows["placement"] = {"input": host_placement(big), "reused_output": host_placement(back)}
     return rows
+
+
+def host_placement(arr):
+    """Where a host array's pages lie (NUMA nodes, share in transparent huge pages) and which CPU the caller is on: the host
+    tier's 1-GiB rows move by 15 % with these (profiles/r03_host_numa_placement.jsonl), so the line says what it ran on."""
+    out = {}
+    try:
+        addr = arr.ctypes.data + arr.nbytes // 2  # the middle: an madvise'd array is several mappings (numpy advises its interior)
+        start = None
+        for line in open("/proc/self/maps"):
+            lo, hi = (int(x, 16) for x in line.split()[0].split("-"))
+            if lo <= addr < hi:
+                start = lo
+                break
+        if start is not None:
+            for line in open("/proc/self/numa_maps"):
+                f = line.split()
+                if int(f[0], 16) == start:
+                    out["pages_per_node"] = {x.split("=")[0]: int(x.split("=")[1]) for x in f[2:] if x[0] == "N" and x[1:2].isdigit()}
+                    break
+            want, size, huge = "%x-" % start, None, None
+            hit = False
+            for line in open("/proc/self/smaps"):
+                if line.startswith(want):
+                    hit = True
+                elif hit and line.startswith("Size:"):
+                    size = int(line.split()[1])
+                elif hit and line.startswith("AnonHugePages:"):
+                    huge = int(line.split()[1])
+                    break
+            if size:
+                out["huge_page_share"] = round(huge / size, 3)
+        cpu = ctypes.CDLL(None).sched_getcpu()
+        node = [d for d in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu) if d.startswith("node")]
+        out["caller_cpu"] = cpu
+        out["caller_node"] = node[0] if node else None
+    except (OSError, ValueError, AttributeError, IndexError):
+        pass
+    return out
+
+
+def gpu_numa_node(bdf):
+    try:
+        return int(open("/sys/bus/pci/devices/%s/numa_node" % str(bdf).lower()).read())
+    except (OSError, ValueError):
+        return None
 
 
 def crossover(host_rows, cpu_rows):
@@ -1210,6 +1257,7 @@ def main():
                             "`fresh out` allocates the output inside the timed call like the reference's functions do; microseconds per call "
                             "at 2^k nt (GiB/s of the fresh-out calls are in the crossover table)",
                     "log2_nt": list(HOST_TIER_LOG2),
+                    "placement": dict(rows["placement"], gpu_numa_node=gpu_numa_node(ident.get("pci_bus_id"))),
                     "us_per_call": {nm: [rows["2^%d" % k][nm + " us"] for k in HOST_TIER_LOG2] for nm in names},
                     "crossover_vs_one_cpu_thread": crossover(rows, cpu_rows)}
         print(json.dumps(line), flush=True)

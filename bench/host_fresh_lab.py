@@ -5,7 +5,8 @@ per setting (the knobs are read once per process).  (profiles/r03_host_fresh_lab
 were produced by an earlier version of this script, which also had rows for the fault-in helper team that round 3 built,
 measured and removed: CNT_HOST_PREFAULT / CNT_HOST_PREFAULT_THREADS in their `env` columns; r03_host_copy_blocks.jsonl and
 r03_host_numa_placement.jsonl by versions with lab-only knobs of the copy pool, see their first lines.)  CNT_LAB_PIN = gpu | other
-confines the CHILD (caller, its data and the library's helpers) to the CPUs of the GPU's NUMA node / of another node.
+confines the CHILD (caller, its data and the library's helpers) to the CPUs of the GPU's NUMA node / of another node;
+CNT_LAB_DATA_NODE does so only while the inputs are created (first touch), CNT_LAB_CALLER_NODE moves the caller afterwards.
 
     python bench/host_fresh_lab.py [--log2-nt 30] [--reps 8]
 
@@ -28,6 +29,8 @@ SETTINGS = [
     ("default, run 2", {}),
     ("caller and its data on the GPU's NUMA node", {"CNT_LAB_PIN": "gpu"}),
     ("caller and its data on the other node", {"CNT_LAB_PIN": "other"}),
+    ("data first touched on the other node, caller unpinned", {"CNT_LAB_DATA_NODE": "other"}),
+    ("data on the GPU's node, caller on the other node", {"CNT_LAB_DATA_NODE": "gpu", "CNT_LAB_CALLER_NODE": "other"}),
     ("no huge-page advice (numpy still advises its own allocations)", {"CNT_HOST_HUGEPAGE": "0"}),
     ("2 pipeline slots (rounds 1-2)", {"CNT_HOST_SLOTS": "2"}),
     ("4 pipeline slots", {"CNT_HOST_SLOTS": "4"}),
@@ -67,6 +70,8 @@ def pin(where):
 
 def child(log2_nt, reps):
     pinned = pin(os.environ["CNT_LAB_PIN"]) if os.environ.get("CNT_LAB_PIN") else None
+    everything = os.sched_getaffinity(0)
+    data_pin = pin(os.environ["CNT_LAB_DATA_NODE"]) if os.environ.get("CNT_LAB_DATA_NODE") else None  # only while the inputs are created
     import numpy as np
 
     from cute_nucleotides_amd import _lib
@@ -78,6 +83,13 @@ def child(log2_nt, reps):
     n = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, m, dtype=np.uint8)]
     bits = np.empty(words, dtype=np.uint64)
     back = np.empty(m, dtype=np.uint8)
+    bits[:] = 0
+    back[:] = 0
+    if data_pin:
+        os.sched_setaffinity(0, everything)  # the data stay where they were first touched; the caller may run anywhere again
+        pinned = {"data": data_pin}
+        if os.environ.get("CNT_LAB_CALLER_NODE"):
+            pinned["caller"] = pin(os.environ["CNT_LAB_CALLER_NODE"])
     p = lambda a: ctypes.c_void_p(a.ctypes.data)
     assert L.cnt_n_to_bits(p(n), m, p(bits), words) == 0 and L.cnt_bits_to_n(p(bits), words, m, p(back)) == 0
     assert np.array_equal(back, n)
