@@ -6,7 +6,8 @@ were produced by an earlier version of this script, which also had rows for the 
 measured and removed: CNT_HOST_PREFAULT / CNT_HOST_PREFAULT_THREADS in their `env` columns; r03_host_copy_blocks.jsonl and
 r03_host_numa_placement.jsonl by versions with lab-only knobs of the copy pool, see their first lines.)  CNT_LAB_PIN = gpu | other
 confines the CHILD (caller, its data and the library's helpers) to the CPUs of the GPU's NUMA node / of another node;
-CNT_LAB_DATA_NODE does so only while the inputs are created (first touch), CNT_LAB_CALLER_NODE moves the caller afterwards.
+CNT_LAB_DATA_NODE does so only while the inputs are created (first touch); with CNT_LAB_CALLER_NODE the caller is a second
+thread confined to that node while the process keeps its full mask.
 
     python bench/host_fresh_lab.py [--log2-nt 30] [--reps 8]
 
@@ -30,7 +31,8 @@ SETTINGS = [
     ("caller and its data on the GPU's NUMA node", {"CNT_LAB_PIN": "gpu"}),
     ("caller and its data on the other node", {"CNT_LAB_PIN": "other"}),
     ("data first touched on the other node, caller unpinned", {"CNT_LAB_DATA_NODE": "other"}),
-    ("data on the GPU's node, caller on the other node", {"CNT_LAB_DATA_NODE": "gpu", "CNT_LAB_CALLER_NODE": "other"}),
+    ("data on the other node, caller thread on the other node", {"CNT_LAB_DATA_NODE": "other", "CNT_LAB_CALLER_NODE": "other"}),
+    ("data on the GPU's node, caller thread on the other node", {"CNT_LAB_DATA_NODE": "gpu", "CNT_LAB_CALLER_NODE": "other"}),
     ("no huge-page advice (numpy still advises its own allocations)", {"CNT_HOST_HUGEPAGE": "0"}),
     ("2 pipeline slots (rounds 1-2)", {"CNT_HOST_SLOTS": "2"}),
     ("4 pipeline slots", {"CNT_HOST_SLOTS": "4"}),
@@ -86,10 +88,32 @@ def child(log2_nt, reps):
     bits[:] = 0
     back[:] = 0
     if data_pin:
-        os.sched_setaffinity(0, everything)  # the data stay where they were first touched; the caller may run anywhere again
+        os.sched_setaffinity(0, everything)  # the data stay where they were first touched; the process may run anywhere again
         pinned = {"data": data_pin}
-        if os.environ.get("CNT_LAB_CALLER_NODE"):
-            pinned["caller"] = pin(os.environ["CNT_LAB_CALLER_NODE"])
+    if os.environ.get("CNT_LAB_CALLER_NODE"):
+        # the CALLER is a second thread confined to one node; the process (its main thread) keeps the full mask, which is
+        # what the library looks at when it places its helpers
+        import threading
+
+        result = {}
+
+        def body():
+            result["caller"] = pin(os.environ["CNT_LAB_CALLER_NODE"])
+            result["rows"] = measure(np, L, n, m, words, bits, back, reps)
+
+        t = threading.Thread(target=body)
+        t.start()
+        t.join()
+        rows = result["rows"]
+        rows["pin"] = dict(pinned or {}, caller=result["caller"])
+        print(json.dumps(rows))
+        return
+    rows = measure(np, L, n, m, words, bits, back, reps)
+    rows["pin"] = pinned
+    print(json.dumps(rows))
+
+
+def measure(np, L, n, m, words, bits, back, reps):
     p = lambda a: ctypes.c_void_p(a.ctypes.data)
     assert L.cnt_n_to_bits(p(n), m, p(bits), words) == 0 and L.cnt_bits_to_n(p(bits), words, m, p(back)) == 0
     assert np.array_equal(back, n)
@@ -134,24 +158,13 @@ def child(log2_nt, reps):
     assert L.cnt_bits_to_n(p(bits), words, m, p(out)) == 0 and np.array_equal(out, n)
     rows["fresh_over_reused"] = {"n_to_bits_hip": round(rows["n_to_bits_hip fresh"]["ms"] / rows["n_to_bits_hip reused"]["ms"], 3),
                                  "bits_to_n_hip": round(rows["bits_to_n_hip fresh"]["ms"] / rows["bits_to_n_hip reused"]["ms"], 3)}
-    rows["pin"] = pinned
-    try:  # where did the big mappings of this process land?  (the pinned staging buffers are 3 x 16 MiB + 3 x 4 MiB and 3 x 4 + 3 x 16)
-        big = []
-        for line in open("/proc/self/numa_maps"):
-            f = line.split()
-            pages = {k: int(v) for k, v in (x.split("=") for x in f[2:] if "=" in x and x.split("=")[0] in ("N0", "N1", "N2", "N3"))}
-            if 1024 <= sum(pages.values()) <= 8192 and "heap" not in line and "stack" not in line:
-                big.append((sum(pages.values()), pages, [x for x in f[2:] if x.startswith(("file=", "anon", "huge", "kernelpagesize"))][:2]))
-        rows["mappings_4_to_32MiB"] = big[:40]
-    except OSError:
-        pass
     try:
         cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else ctypes.CDLL(None).sched_getcpu()
         node = [d for d in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu) if d.startswith("node")]
         rows["caller_cpu_at_end"] = {"cpu": cpu, "node": node[0] if node else None}
     except OSError:
         pass
-    print(json.dumps(rows))
+    return rows
 
 
 if __name__ == "__main__":
