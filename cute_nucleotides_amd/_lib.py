@@ -71,6 +71,7 @@ SIGNATURES = {
     "cnt_get_tuning": (_int, [ctypes.c_char_p, ctypes.POINTER(_int)]),
     "cnt_tuning_name": (ctypes.c_char_p, [ctypes.c_char_p, _int]),
     "cnt_chip_info": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "cnt_check_device_range": (_int, [ctypes.c_void_p, ctypes.c_size_t, _int]),
     "cnt_test_alias_devices": (_int, [_int]),
 }
 

@@ -404,6 +404,42 @@ int cnt_chip_info(int device, int* compute_units, int* lds_bytes_per_cu, int* xc
     return CNT_OK;
 }
 
+// Debug aid for FFI callers of the *_dev entry points (they take raw device pointers and only enqueue: a host pointer or a
+// pointer of another device's memory is a GPU page fault -- a process abort -- when the kernel runs, not an error code).
+int cnt_check_device_range(const void* p, size_t bytes, int device) {
+    if (!p) return CNT_EINVAL;
+    int count = 0, cur = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return CNT_ENODEV;
+    if (device < 0) {
+        HIP_TRY(hipGetDevice(&cur));
+        device = cur;
+    }
+    if (device >= count) return CNT_ENODEV;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return CNT_EINVAL;  // ordinary (pageable) host memory or not a mapping at all
+    }
+    if (a.type == hipMemoryTypeDevice && a.device != device) {
+        int peer = 0;  // another device's memory: fine only where peer access is enabled -- the library never enables it
+        if (hipDeviceCanAccessPeer(&peer, device, a.device) != hipSuccess || !peer) return CNT_EINVAL;
+    } else if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeHost && a.type != hipMemoryTypeManaged) {
+        return CNT_EINVAL;
+    }
+    if (bytes) {
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        const void* dp = a.type == hipMemoryTypeHost && a.devicePointer ? a.devicePointer : p;
+        if (hipMemGetAddressRange(&base, &size, const_cast<void*>(dp)) != hipSuccess) {
+            (void)hipGetLastError();
+            return CNT_OK;  // pinned host memory registered by the caller has no range to ask for: the type check stands
+        }
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(dp), end = reinterpret_cast<uintptr_t>(base) + size;
+        if (lo + bytes < lo || lo + bytes > end) return CNT_ECAP;
+    }
+    return CNT_OK;
+}
+
 int cnt_test_alias_devices(int on) { return g_alias_devices.exchange(on ? 1 : 0); }
 
 const char* cnt_tuning_name(const char* key, int value) {

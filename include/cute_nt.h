@@ -250,6 +250,14 @@ const char *cnt_tuning_name(const char *key, int value);
  * reductions' grids and the XCD-aware tile maps follow).  Any pointer may be NULL. */
 int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xcds);
 
+/* Debug aid for callers of the *_dev entry points, which take raw pointers and only enqueue: a host pointer or another
+ * device's memory there is a GPU page fault (a process abort) when the kernel runs, not an error code.  CNT_OK if
+ * [p, p + bytes) lies inside ONE allocation that `device` (-1 = the calling thread's current device) can address: its own
+ * memory, pinned / mapped host memory, managed memory, or a peer's memory where the hardware allows peer access.
+ * CNT_EINVAL for pageable host memory and unreachable devices' memory, CNT_ECAP when the range runs past the
+ * allocation's end.  Costs two runtime queries (microseconds): for debug builds and tests, not for hot loops. */
+int cnt_check_device_range(const void *p, size_t bytes, int device);
+
 /* ---- environment variables the host tiers read (all optional) -------------------
  *   CNT_HOST_COPY_THREADS        staging-copy threads per calling thread (default 4, 1 = none); copy-outs into outputs
  *                                whose pages do not exist yet (a fresh Vec) use twice as many.  The helpers spin for up

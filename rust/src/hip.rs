@@ -33,6 +33,7 @@ extern "C" {
     fn cnt_dev_upload(d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     fn cnt_dev_download(h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     fn cnt_dev_sync(stream: *mut c_void) -> c_int;
+    fn cnt_check_device_range(p: *const c_void, bytes: usize, device: c_int) -> c_int;
     fn cnt_shutdown() -> c_int;
     // packed-domain operations (host tier): what the reference's README points to, on the packed words
     fn cnt_hamming(a: *const u64, b: *const u64, len: usize, distance: *mut u64) -> c_int;
@@ -290,6 +291,13 @@ pub fn bits_to_n_hip_dev(d_bits: &DeviceBuffer, words: usize, len: usize, d_out:
     }
     assert!(words * 8 <= d_bits.bytes && len <= d_out.bytes);
     unsafe { check(cnt_bits_to_n_dev(d_bits.ptr, words, len, d_out.ptr, 0, std::ptr::null_mut())) };
+}
+
+/// Debug aid for code that hands RAW device pointers to the `*_dev` entry points (a host pointer there is a GPU page
+/// fault when the kernel runs, not an error): true if `[p, p + bytes)` lies inside one allocation the current device
+/// can address.
+pub fn check_device_range(p: *const c_void, bytes: usize) -> bool {
+    unsafe { cnt_check_device_range(p, bytes, -1) == 0 }
 }
 
 /// Wait for everything enqueued on the default stream.

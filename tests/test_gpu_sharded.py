@@ -338,3 +338,27 @@ def test_chip_info_is_what_the_launchers_use(L):
     if "MI355" in props.name and cus.value == 256:
         assert (lds.value, xcds.value) == (163840, 8)
     assert L.cnt_chip_info(torch.cuda.device_count(), None, None, None) != 0
+
+
+def test_check_device_range_tells_device_memory_from_host_memory():
+    """cnt_check_device_range: the debug aid for FFI callers of the *_dev entry points (a wrong pointer there is a GPU page
+    fault, not an error code)."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    d = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    p = ctypes.c_void_p
+    assert L.cnt_check_device_range(p(d.data_ptr()), d.numel(), -1) == 0
+    assert L.cnt_check_device_range(p(d.data_ptr() + 12345), d.numel() - 12345, 0) == 0  # interior pointers are fine
+    assert L.cnt_check_device_range(p(d.data_ptr()), 1 << 40, 0) == _lib.CNT_ECAP  # runs past the allocation
+    host = np.zeros(4096, dtype=np.uint8)
+    assert L.cnt_check_device_range(p(host.ctypes.data), 4096, 0) == _lib.CNT_EINVAL  # pageable host memory
+    assert L.cnt_check_device_range(None, 16, 0) == _lib.CNT_EINVAL
+    pinned = torch.empty(4096, dtype=torch.uint8, pin_memory=True)
+    assert L.cnt_check_device_range(p(pinned.data_ptr()), 4096, 0) == 0  # pinned host memory is addressable by the device
+    assert L.cnt_check_device_range(p(d.data_ptr()), 16, torch.cuda.device_count()) == _lib.CNT_ENODEV
