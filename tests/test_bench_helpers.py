@@ -82,3 +82,17 @@ def test_bench_refuses_cleanly_without_a_gpu():
                              capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
         assert out.returncode != 0 and out.stdout.strip() == "", (extra, out.stdout[-300:])
         assert "no HIP device visible" in out.stderr and "Traceback" not in out.stderr, (extra, out.stderr[-600:])
+
+
+def test_host_placement_reads_this_process():
+    """bench.py's host_tier.placement block: NUMA nodes / huge-page share of a big array and the caller's CPU, from /proc and
+    /sys -- must never raise, and on Linux it finds the array's pages (all of them touched here)."""
+    import bench
+
+    a = np.ones(64 << 20, dtype=np.uint8)
+    p = bench.host_placement(a)
+    assert isinstance(p, dict)
+    if os.path.exists("/proc/self/numa_maps"):
+        assert sum(p["pages_per_node"].values()) * 4096 >= a.nbytes // 2 and 0.0 <= p["huge_page_share"] <= 1.0
+        assert p["caller_cpu"] >= 0
+    assert bench.gpu_numa_node("0000:ff:1f.7") is None and bench.gpu_numa_node(None) is None  # no such device: no answer, no exception
