@@ -234,8 +234,14 @@ def cpu_baseline(seconds):
 
 
 def stats_ms(ms):
-    return {"mean": round(statistics.fmean(ms), 4), "median": round(statistics.median(ms), 4), "min": round(min(ms), 4),
-            "max": round(max(ms), 4), "n": len(ms)}
+    """mean / median / min / max and, from 10 samples on, p10 / p90 (decode's launches spread 3-9 % on one box with the
+    clock flat: profiles/r04_decode_spread.md -- a mean alone hides that)"""
+    s = sorted(ms)
+    out = {"mean": round(statistics.fmean(ms), 4), "median": round(statistics.median(ms), 4), "min": round(s[0], 4),
+           "max": round(s[-1], 4), "n": len(ms)}
+    if len(s) >= 10:
+        out["p10"], out["p90"] = round(s[len(s) // 10], 4), round(s[(9 * len(s)) // 10], 4)
+    return out
 
 
 def gbs(nbytes, ms):

@@ -27,7 +27,8 @@ TCC_CHANNELS = 128  # 16 channels x 8 XCDs
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     log2_nt = int(sys.argv[2]) if len(sys.argv) > 2 else 34
-    src = os.path.join(ROOT, "gpurun_out", "pmc_bound_" + tag)
+    what = sys.argv[3] if len(sys.argv) > 3 else "codec2"
+    src = os.path.join(ROOT, "gpurun_out", "pmc_bound_" + tag + ("" if what == "codec2" else "_" + what))
     n = 1 << log2_nt
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     durations = collections.defaultdict(list)
@@ -50,6 +51,16 @@ def main():
             ("read4:write1 probe + encode arithmetic x4", "shipped::k_r4w1_arith<64, 2, 1, 2, 19, 4>", n, n // 4),
             ("n_to_bits_stream (encode)", "cnt::n_to_bits_stream<", n, n // 4), ("bits_to_n_stream (decode)", "cnt::bits_to_n_stream<", n // 4, n),
             ("round_trip_stream (fused)", "cnt::round_trip_stream<", n, n + n // 4)]
+    if what == "codec5":  # bench/pmc_bound_workload.py --what codec5: whole wave tiles of 128 words
+        words = (n // 27) // 128 * 128
+        a5, w5 = 27 * words, 8 * words
+        n = a5
+        want = [("5-letter encode (n_to_bits2_wave, shipped)", "cnt::n_to_bits2_wave<", a5, w5),
+                ("  encode's loads + LDS staging + stores, no arithmetic", "shipped::k_enc5<1", a5, w5),
+                ("  encode's loads + stores, no LDS", "shipped::k_enc5<2", a5, w5),
+                ("5-letter decode (bits_to_n2_wave, shipped)", "cnt::bits_to_n2_wave<", w5, a5),
+                ("  decode's loads + LDS staging + stores, no arithmetic", "shipped::k_dec5<1", w5, a5),
+                ("  decode's loads + stores, no LDS", "shipped::k_dec5<2", w5, a5)]
     out = {"tag": tag, "nt": n, "tcc_channels": TCC_CHANNELS,
            "note": "bench/pmc_bound.sh over bench/pmc_bound_workload.py; counters are sums over all L2 channels, mean per launch; "
                    "durations are under the profiler (PMC passes), median over all passes", "kernels": {}}
@@ -83,7 +94,7 @@ def main():
                     d[name] = round(c[key] / c["TCC_BUSY"], 4)
         row["derived"] = d
         out["kernels"][label] = row
-    dst = os.path.join(ROOT, "profiles", tag + "_bound_counters.json")
+    dst = os.path.join(ROOT, "profiles", tag + ("_bound_counters.json" if what == "codec2" else "_bound_counters_%s.json" % what))
     json.dump(out, open(dst, "w"), indent=1)
     for label, row in out["kernels"].items():
         print(label, json.dumps({k: v for k, v in row.items() if k in ("median_ms_under_pmc", "GBs_total", "GBs_read", "derived")}))

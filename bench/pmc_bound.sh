@@ -6,8 +6,10 @@
 # profiles/TAG_bound_counters.json.
 set -u
 TAG=${1:-r02}
+WHAT=${2:-codec2}   # codec2 | codec5 (the second writes gpurun_out/pmc_bound_${TAG}_codec5)
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/pmc_bound_$TAG
+[ "$WHAT" = codec2 ] || OUT=${OUT}_$WHAT
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
@@ -18,6 +20,6 @@ for set in \
   "TCC_TAG_STALL TCC_TOO_MANY_EA_WRREQS_STALL TCC_IB_STALL TCC_REQ" \
   "TCC_EA0_RDREQ_32B TCC_EA0_WRREQ_64B TCC_EA0_WR_UNCACHED_32B TCC_CYCLE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/$i" -o pmc -- python "$REPO/bench/pmc_bound_workload.py" > "$OUT/$i.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/$i" -o pmc -- python "$REPO/bench/pmc_bound_workload.py" --what "$WHAT" > "$OUT/$i.log" 2>&1
   echo "pass $i ($set) rc=$?"
 done

@@ -18,7 +18,32 @@ from cute_nucleotides_amd import devutil  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)
 ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--what", choices=("codec2", "codec5"), default="codec2")
 a = ap.parse_args()
+if a.what == "codec5":
+    # the 5-letter codec at the metric size (2^34 nt rounded to whole wave tiles): shipped encode / decode beside their
+    # arithmetic-free twins with and without the LDS staging (bench/probes.hip probe_codec5)
+    words = ((1 << a.log2_nt) // 27) // 128 * 128
+    n5 = 27 * words
+    d_n = torch.empty(n5 + 256, dtype=torch.uint8, device="cuda")[:n5]
+    d_w = torch.empty(words, dtype=torch.int64, device="cuda")
+    d_b = torch.empty(n5 + 256, dtype=torch.uint8, device="cuda")[:n5]
+    devutil.fill_random_acgtn(d_n, 0x5EED)
+    P = ctypes.CDLL(os.path.join(ROOT, "bench", "libcnt_probes.so"))
+    P.probe_codec5.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scratch_w = torch.empty(words, dtype=torch.int64, device="cuda")
+    for _ in range(a.reps):
+        for kind in (1, 2):
+            assert P.probe_codec5(kind, d_n.data_ptr(), scratch_w.data_ptr(), words, s) == 0
+        cn.n_to_bits2_dev(d_n, out=d_w)
+        for kind in (3, 4):
+            assert P.probe_codec5(kind, d_w.data_ptr(), d_b.data_ptr(), words, s) == 0
+        cn.bits_to_n2_dev(d_w, n5, out=d_b)
+    torch.cuda.synchronize()
+    assert devutil.count_mismatch(d_n, d_b) == 0
+    print("pmc bound workload (codec5) ok: %d words, reps = %d" % (words, a.reps))
+    sys.exit(0)
 n = 1 << a.log2_nt
 d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
 d_packed = torch.empty(n // 32, dtype=torch.int64, device="cuda")

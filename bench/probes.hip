@@ -17,6 +17,7 @@
 
 #include "../cute_nucleotides_amd/csrc/codec2_kernels.hpp"
 #include "../cute_nucleotides_amd/csrc/codec2_launch.hpp"
+#include "../cute_nucleotides_amd/csrc/codec5_kernels.hpp"
 
 using cnt::u32x4;
 constexpr int kBlock = 256;
@@ -225,6 +226,94 @@ __global__ __launch_bounds__(BLOCK) void k_r4w1_arith(const uint8_t* __restrict_
         __builtin_amdgcn_raw_buffer_store_b32(c, rout, (u * BLOCK + threadIdx.x) * 4, 0, SAUX);
     }
 }
+
+// ---- the 5-letter codec's access patterns without its arithmetic (round 2's tune_lab16, now countable by rocprofv3) ----
+// One wave per tile of 128 words: 3456 B of ASCII (27 lines: three full 1-KiB wave loads and one of 24 lanes) on the
+// wide side, 1 KiB of words (two 8-B accesses per lane) on the narrow side -- exactly the shipped kernels' global
+// instructions, cache policies, tile maps and residency.  MODE 1 keeps the LDS staging (16-B writes, wave fence, 8 dword
+// reads per word / 6-7 dword writes per word and 16-B reads) with trivial arithmetic; MODE 2 has no LDS traffic at all.
+template <int MODE, int LAUX, int SAUX>
+__global__ __launch_bounds__(64) void k_enc5(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles) {
+    constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
+    __shared__ __attribute__((aligned(16))) uint32_t my[kWaveDwords5 * WPL + 4];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, TILE_BYTES);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
+    constexpr int NLD = (TILE_VECS + 63) / 64;
+    u32x4 v[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        v[i] = u32x4{0, 0, 0, 0};
+        if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64))
+            v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
+    }
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64)) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const uint32_t q = (27u * lane + (uint32_t)kWaveBytes5 * j) >> 2;
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (int d = 0; d < 8; d += 2) { a ^= my[q + d]; b ^= my[q + d + 1]; }
+            const vu2 w2 = {a, b};
+            __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
+        }
+    } else {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) { a ^= v[i].x ^ v[i].z; b ^= v[i].y ^ v[i].w; }
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const vu2 w2 = {a + j, b};
+            __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
+        }
+        if (n_tiles == ~0ull) my[lane] = a;  // keeps the static slab (and with it the residency) attached
+    }
+}
+template <int MODE, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(64) void k_dec5(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_tiles, uint32_t xs) {
+    constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
+    __shared__ __attribute__((aligned(16))) uint32_t my[kWaveDwords5 * WPL + 4];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, (uint32_t)n_tiles, xs);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * (TILE_WORDS * 8), TILE_WORDS * 8);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_BYTES, TILE_BYTES);
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    vu2 w2[WPL];
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
+    constexpr int NST = (TILE_VECS + 63) / 64;
+    if constexpr (MODE == 1) {
+        const uint32_t byte0 = 27u * lane, q0 = byte0 >> 2, cnt = ((byte0 + 27u) >> 2) - q0;
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            uint32_t* dst = my + kWaveDwords5 * j + q0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dst[k] = w2[j][k & 1] + (uint32_t)k;
+            if (cnt == 7) dst[6] = w2[j][0];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64)) {
+                const u32x4 o = *reinterpret_cast<const u32x4*>(my + (i * 64 + lane) * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if ((i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64)) {
+                const u32x4 o = {w2[0][0] + (uint32_t)i, w2[0][1], w2[1][0], w2[1][1]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
+            }
+        if (n_tiles == ~0ull) my[lane] = w2[0][0];
+    }
+}
 }  // namespace shipped
 
 // kind 0 read-only (1024 thr x 1 load, nt) | 1 copy 1:1 (256 thr x 1, ld=nt st=sc0|sc1|nt) |
@@ -253,6 +342,30 @@ extern "C" int probe_shipped(int kind, const void* a, void* b, size_t bytes, voi
         case 21: CNT_P41(1) case 22: CNT_P41(2) case 24: CNT_P41(4) case 28: CNT_P41(8)
 #undef CNT_P14
 #undef CNT_P41
+        default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// The 5-letter codec's streams without its arithmetic, launched like the shipped defaults (encode2 variant 0: plain order,
+// ld=nt st=sc1, 15 wg/CU; decode2 variant 0: XCD quads, ld=plain st=sc0|sc1|nt, 16 wg/CU).  kind 1 / 2: encode's pattern
+// with / without the LDS staging (a = ASCII, b = words); kind 3 / 4: decode's (a = words, b = ASCII).  `words` must be a
+// multiple of 128 (whole wave tiles).  Returns 0 / 1 (bad argument) / 2 (launch).
+extern "C" int probe_codec5(int kind, const void* a, void* b, size_t words, void* stream) {
+    using namespace cnt;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint8_t* pa = static_cast<const uint8_t*>(a);
+    uint8_t* pb = static_cast<uint8_t*>(b);
+    if (words == 0 || (words & 127) || (words >> 7) > 0x7FFFFFFFull / 64) return 1;
+    const uint64_t tiles = words >> 7;
+    constexpr int kAll = kSC0 | kSC1 | kNT;
+    const uint32_t xs = xcd_shift();
+    const uint32_t lds15 = lds_for_cap(15) > 3584u ? lds_for_cap(15) - 3584u : 0u, lds16 = lds_for_cap(16) > 3584u ? lds_for_cap(16) - 3584u : 0u;
+    switch (kind) {
+        case 1: hipLaunchKernelGGL((shipped::k_enc5<1, kNT, kSC1>), dim3((unsigned)tiles), dim3(64), lds15, s, pa, pb, tiles); break;
+        case 2: hipLaunchKernelGGL((shipped::k_enc5<2, kNT, kSC1>), dim3((unsigned)tiles), dim3(64), lds15, s, pa, pb, tiles); break;
+        case 3: hipLaunchKernelGGL((shipped::k_dec5<1, 4, 0, kAll>), dim3((unsigned)tiles), dim3(64), lds16, s, pa, pb, tiles, xs); break;
+        case 4: hipLaunchKernelGGL((shipped::k_dec5<2, 4, 0, kAll>), dim3((unsigned)tiles), dim3(64), lds16, s, pa, pb, tiles, xs); break;
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
+#include <thread>
 
 #include "codec2_kernels.hpp"
 
@@ -48,12 +50,22 @@ inline ChipInfo query_chip(int device) {
 inline const ChipInfo& chip_info() {  // of the calling thread's current device
     constexpr int kMaxDev = 64;
     static ChipInfo table[kMaxDev];
-    static std::atomic<uint8_t> ready[kMaxDev];
+    static std::atomic<uint8_t> state[kMaxDev];  // 0 = empty, 1 = one thread is filling it, 2 = ready
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    if (!ready[dev].load(std::memory_order_acquire)) {
-        table[dev] = query_chip(dev);  // racing threads write the same answer
-        ready[dev].store(1, std::memory_order_release);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev >= kMaxDev) {  // beyond the cache: ask every time rather than quote device 0's geometry
+        static thread_local ChipInfo uncached;
+        uncached = query_chip(dev);
+        return uncached;
+    }
+    if (state[dev].load(std::memory_order_acquire) != 2) {
+        uint8_t expect = 0;
+        if (state[dev].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
+            table[dev] = query_chip(dev);  // exactly one writer
+            state[dev].store(2, std::memory_order_release);
+        } else {
+            while (state[dev].load(std::memory_order_acquire) != 2) std::this_thread::yield();  // three attribute queries away
+        }
     }
     return table[dev];
 }
@@ -71,6 +83,12 @@ inline uint32_t xcd_shift() {
 
 // dynamic-LDS bytes that let `cap` workgroups (and no more) fit in a CU's LDS (160 KiB on gfx950)
 inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (chip_info().lds_per_cu / cap) / 256u * 256u : 0u; }
+// the same for a kernel that already owns `static_bytes` of LDS: the dynamic part that completes the cap, saturating (on a
+// 64-KiB-LDS part a 10-per-CU cap is 6400 B, below the 7168-B slab of the four-words-per-lane variants: no padding then)
+inline uint32_t lds_pad_for_cap(uint32_t cap, uint32_t static_bytes) {
+    const uint32_t total = lds_for_cap(cap);
+    return total > static_bytes ? total - static_bytes : 0u;
+}
 
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
@@ -201,7 +219,7 @@ constexpr uint32_t kWindowEncodeSlack = 144;  // bytes a tile may read behind it
 template <bool STRICT>
 void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64);
-    const uint32_t lds = lds_for_cap(23);  // doubles as the kernel's 768-B exchange slab
+    const uint32_t lds = std::max(lds_for_cap(23), 768u);  // doubles as the kernel's 768-B exchange slab
     const uint32_t xs = xcd_shift();
     e.tail_first = e.head_words + total_tiles * (kWindowEncodeTile / 32);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {

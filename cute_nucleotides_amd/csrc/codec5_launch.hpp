@@ -104,7 +104,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
         e.groups = (one_wave && first + n == total) ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         // the static slab is 3488 B (2 words per lane) / 6944 B (4 words per lane), allocated in 512-B granules
         const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;
-        const uint32_t lds = kEncode2Variants[variant].wg_cap ? lds_for_cap(kEncode2Variants[variant].wg_cap) - slab : 0u;
+        const uint32_t lds = lds_pad_for_cap(kEncode2Variants[variant].wg_cap, slab);
 #define CNT_ENC2(W, P, L, S) \
     hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
         switch (variant) {
@@ -139,7 +139,7 @@ template <bool STRICT>
 void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, Encode2Edges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
     const uint32_t xs = xcd_shift();
-    const uint32_t lds = lds_for_cap(kEncode2Variants[0].wg_cap) - 3584u - 128u;  // the window slab is 128 B larger than variant 0's
+    const uint32_t lds = lds_pad_for_cap(kEncode2Variants[0].wg_cap, 3584u + 128u);  // the window slab is 128 B larger than variant 0's
     e.tail_first = e.head_words + total_tiles * (kWindowEncode2Tile / 27);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n = total_tiles - first < per_launch ? total_tiles - first : per_launch;
@@ -166,7 +166,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_nt;
         e.groups = (one_wave && first + n == total) ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;  // static slab, see launch_encode2
-        const uint32_t lds = kDecode2Variants[variant].wg_cap ? lds_for_cap(kDecode2Variants[variant].wg_cap) - slab : 0u;
+        const uint32_t lds = lds_pad_for_cap(kDecode2Variants[variant].wg_cap, slab);
 #define CNT_DEC2(W, P, L, S) \
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
         switch (variant) {

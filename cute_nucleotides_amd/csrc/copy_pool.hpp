@@ -14,12 +14,18 @@
 #include <thread>
 #include <vector>
 
+#ifndef CNT_COPY_POOL_TEST_STALL
+#define CNT_COPY_POOL_TEST_STALL(k) ((void)0)
+#endif
+
 // ---- per-thread host-copy helpers ---------------------------------------------------
 // The host tier stages caller memory through pinned buffers (measured on MI355X / PCIe Gen5,
 // profiles/r01_host_tier_lab.log: pageable hipMemcpyAsync runs at 43 GB/s only after the runtime
 // has pinned the caller's pages and at 8-14 GB/s on first touch; explicit staging is 20-25 GB/s
 // with one copying thread and ~40 GB/s with four, cold or warm).  A small team of helper threads per calling
-// thread does the staging copies with it; CNT_HOST_COPY_THREADS (default 4, 1 = no helpers) sizes it.
+// thread does the staging copies with it; CNT_HOST_COPY_THREADS (default 4, 1 = no helper threads at all) sizes the team
+// of warm copies, the caller included; copies into fresh pages use twice that team, so a calling thread owns up to
+// 2 x team - 1 helper threads (7 at the default), each spinning for up to 150 us after a copy before it sleeps.
 class CopyPool {
    public:
     ~CopyPool() { stop(); }
@@ -34,7 +40,7 @@ class CopyPool {
     // 20-50 us of a condition-variable wake-up (which made 8 threads SLOWER than 4 in the first version of this pool).
     void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false) {
         const int all = threads();
-        const int T = fresh_pages ? all : std::max(1, all / 2);  // the pool holds twice the warm-copy team
+        const int T = fresh_pages ? all : std::max(1, (all + 1) / 2);  // warm copies use the configured team, fresh ones twice that
         if (bytes < kMinPar || T <= 1) {
             memcpy(dst, src, bytes);
             return;
@@ -45,20 +51,35 @@ class CopyPool {
         const size_t blk = fresh_pages ? kFreshBlock : kWarmBlock;
         const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
         const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
-        job_blk_.store(blk, std::memory_order_relaxed);
+        // Publication order: the block counter moves to generation g FIRST -- from here on nobody can take a
+        // block of the previous job -- and only then are the job's fields and its completion counter rewritten.  A helper
+        // that is still holding generation g-1 and reads any field written below is ordered after the counter's bump (the
+        // fence here pairs with the acquire fence in run()), finds generation g in the counter and returns without touching
+        // anything; before the bump every field it can see belongs to g-1, whose blocks are all taken.  (Round 3 wrote the
+        // block size and reset done_ BEFORE the bump: a helper preempted between its field loads could then combine job
+        // g-1's pointers with job g's smaller block size, compute a larger block count, win one more block of the old job
+        // and add to the new job's completion counter.)
+        next_.store(g << 32, std::memory_order_seq_cst);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
         done_.store(0, std::memory_order_relaxed);
-        next_.store(g << 32, std::memory_order_seq_cst);  // from here on nobody can take a block of the previous job
         job_dst_.store(dst, std::memory_order_relaxed);
         job_src_.store(src, std::memory_order_relaxed);
         job_bytes_.store(bytes, std::memory_order_relaxed);
+        job_blk_.store(blk, std::memory_order_relaxed);
+        job_nblocks_.store(nblocks, std::memory_order_relaxed);
         job_team_.store(T, std::memory_order_relaxed);
         gen_.store(g, std::memory_order_seq_cst);
         if (sleepers_.load(std::memory_order_seq_cst) > 0) {
             std::lock_guard<std::mutex> lk(m_);
             cv_work_.notify_all();
         }
-        work(g, dst, src, bytes, blk);
-        for (unsigned spins = 1; done_.load(std::memory_order_acquire) != nblocks; ++spins) cpu_relax();  // blocks still in other hands: < 30 us
+        work(g, dst, src, bytes, blk, nblocks);
+        // blocks still in other hands: normally < 30 us; a helper that was preempted while holding one can take a scheduler
+        // quantum, so after a short spin the caller yields its CPU instead of burning it
+        for (unsigned spins = 1; done_.load(std::memory_order_acquire) < nblocks; ++spins) {
+            if (spins < 4096) cpu_relax();
+            else std::this_thread::yield();
+        }
     }
     // Sharded tier: worker pools are sized so that the TOTAL over all devices stays bounded
     // (0 = back to CNT_HOST_COPY_THREADS).  Takes effect at the next copy().
@@ -67,7 +88,10 @@ class CopyPool {
         limit_ = n;
         if (started_) stop();
     }
-    int size() const { return started_ ? n_threads_ / 2 : 0; }  // the warm-copy team (what CNT_HOST_COPY_THREADS / the sharded budget count)
+    // the warm-copy team = what CNT_HOST_COPY_THREADS / the sharded budget count (the caller is one of them); threads that
+    // EXIST besides the caller: spawned() -- up to 2 x team - 1, the second half only works on copies into fresh pages
+    int size() const { return started_ ? team_ : 0; }
+    int spawned() const { return started_ ? (int)workers_.size() : 0; }
     void stop() {
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -98,7 +122,9 @@ class CopyPool {
             int t = 4;
             if (const char* e = getenv("CNT_HOST_COPY_THREADS")) t = atoi(e);
             if (limit_ > 0) t = std::min(t, limit_);
-            n_threads_ = 2 * std::max(1, std::min(t, 16));  // warm copies use half of them
+            team_ = std::max(1, std::min(t, 16));
+            // a team of 1 means what the header says: no helper thread at all, every copy is the caller's memcpy
+            n_threads_ = team_ == 1 ? 1 : 2 * team_;  // warm copies use half of them
             const uint64_t seen = gen_.load(std::memory_order_relaxed);
             for (int k = 1; k < n_threads_; ++k) workers_.emplace_back([this, k, seen] { run(k, seen); });
         }
@@ -106,9 +132,8 @@ class CopyPool {
     }
     // take blocks of job `g` until none is left; the generation in the counter's high half keeps a straggler of an
     // older job from ever taking (and losing) a block of this one
-    void work(uint64_t g, uint8_t* dst, const uint8_t* src, size_t bytes, size_t blk) {
+    void work(uint64_t g, uint8_t* dst, const uint8_t* src, size_t bytes, size_t blk, uint64_t nblocks) {
         const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
-        const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
         for (;;) {
             uint64_t cur = next_.load(std::memory_order_acquire);
             if ((cur >> 32) != (g & 0xFFFFFFFFull) || (cur & 0xFFFFFFFFull) >= nblocks) return;
@@ -137,13 +162,19 @@ class CopyPool {
             const uint64_t g = gen_.load(std::memory_order_acquire);
             if (g == seen) continue;
             seen = g;
-            // the job's fields were written before gen_ was: they belong to `g` or to a LATER job, and in the second case
-            // the counter no longer carries `g` and work() returns at once
+            // the job's fields were written before gen_ was and AFTER the block counter moved to their generation (copy()):
+            // they all belong to `g`, or at least one belongs to a LATER job -- and then the acquire fence below orders this
+            // thread behind that job's bump of the counter, which no longer carries `g`, and work() returns at once
             uint8_t* dst = job_dst_.load(std::memory_order_relaxed);
             const uint8_t* src = job_src_.load(std::memory_order_relaxed);
             const size_t bytes = job_bytes_.load(std::memory_order_relaxed);
-            if (k >= job_team_.load(std::memory_order_relaxed)) continue;
-            work(g, dst, src, bytes, job_blk_.load(std::memory_order_relaxed));
+            CNT_COPY_POOL_TEST_STALL(k);  // tests/copy_pool_stress.cpp parks a helper HERE, between its field loads, across whole jobs
+            const size_t blk = job_blk_.load(std::memory_order_relaxed);
+            const uint64_t nblocks = job_nblocks_.load(std::memory_order_relaxed);
+            const int team = job_team_.load(std::memory_order_relaxed);
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (k >= team) continue;
+            work(g, dst, src, bytes, blk, nblocks);
         }
     }
     std::mutex m_;
@@ -153,8 +184,9 @@ class CopyPool {
     std::atomic<uint8_t*> job_dst_{nullptr};
     std::atomic<const uint8_t*> job_src_{nullptr};
     std::atomic<size_t> job_bytes_{0}, job_blk_{0};
+    std::atomic<uint64_t> job_nblocks_{0};
     std::atomic<int> job_team_{0}, sleepers_{0};
     std::atomic<bool> stop_{false};
-    int n_threads_ = 1, limit_ = 0;
+    int n_threads_ = 1, team_ = 1, limit_ = 0;
     bool started_ = false;
 };

@@ -13,7 +13,7 @@
 // One translation unit (the kernel headers define non-template __global__ functions), split for reading:
 //   shim_host_ctx.inc   staging-copy pool, per-thread / per-device context, huge-page advice
 //   device_tier.inc     alignment plan + kernel selection: encode_dev, decode_dev, round_trip_dev, *2_dev
-//   host_tier.inc       zero-copy small calls, 2-slot pinned-staging pipeline
+//   host_tier.inc       zero-copy small calls, pinned-staging pipeline over a ring of 3 (2..4) slots
 //   sharded_tier.inc    partition, NUMA-pinned worker pool, resident-shard runner
 //   (this file)         tuning knobs and every exported symbol of include/cute_nt.h
 //   packed_ops_abi.inc  the packed-domain operations' entry points

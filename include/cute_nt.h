@@ -259,10 +259,14 @@ int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xc
 int cnt_check_device_range(const void *p, size_t bytes, int device);
 
 /* ---- environment variables the host tiers read (all optional) -------------------
- *   CNT_HOST_COPY_THREADS        staging-copy threads per calling thread (default 4, 1 = none); copy-outs into outputs
- *                                whose pages do not exist yet (a fresh Vec) use twice as many.  The helpers spin for up
- *                                to 150 us after a copy before they go to sleep, i.e. for the length of a pipelined call
- *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 3, 2..4)
+ *   CNT_HOST_COPY_THREADS        staging-copy team per calling thread, the caller included (default 4; 1 = no helper thread
+ *                                is ever created); copy-outs into outputs whose pages do not exist yet (a fresh Vec) use
+ *                                twice the team, so up to 2 x team - 1 helper threads exist per calling thread (7 at the
+ *                                default).  The helpers spin for up to 150 us after a copy before they go to sleep, i.e.
+ *                                for the length of a pipelined call
+ *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 3, 2..4).  Footprint per calling thread (and
+ *                                per sharded-tier worker) and device: slots x (16 + 16) MiB of pinned host memory and as much
+ *                                device scratch, grown on demand (96 + 96 MiB at the default), released by cnt_shutdown()
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
@@ -272,7 +276,8 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                units (1-GiB decode into a fresh malloc: 150 -> 72-91 ms per call).  The advice changes
  *                                the caller's VMA flags for good (possible VMA split, huge-page RSS): set 0 if unwanted
  *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
- *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy threads summed over all devices (default 32) */
+ *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy teams summed over all devices (default 32: 8 shards -> teams of
+ *                                4); as above the threads that exist are up to twice that minus one per shard */
 
 /* ---- test support ------------------------------------------------------------------
  * cnt_test_alias_devices(1) lets the sharded tiers accept ndev > visible devices (<= 64) and run

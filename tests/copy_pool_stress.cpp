@@ -3,10 +3,54 @@
 // follow each other at once (the helpers are still spinning) and after a pause (they have gone to sleep), pool restarts,
 // several calling threads with a pool each.  Every copy is compared byte for byte; guard bytes around the
 // destination must survive.  Prints "ok <copies>" and exits 0.
+// Mode "stall" (ADVICE r03): one helper is parked BETWEEN its loads of a job's fields -- after the pointers and the size,
+// before the block size -- while the caller finishes that job (a copy into fresh pages, 2-MiB blocks), frees the buffers
+// and runs the next one (a warm copy, 1-MiB blocks).  With round 3's publication order the helper then combined the old
+// job's pointers with the new block size, took one block too many of the OLD job (a write into freed memory) and bumped
+// the NEW job's completion counter; the test checks that the old destination's canary page stays untouched and that every
+// later copy is complete.
+#include <atomic>
+#include <chrono>
+#include <thread>
+static std::atomic<int> g_stall_armed{0}, g_stalled{0}, g_release{0};
+static void test_stall(int k) {
+    int one = 1;
+    if (k == 1 && g_stall_armed.compare_exchange_strong(one, 2)) {
+        g_stalled.store(1);
+        while (!g_release.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+#define CNT_COPY_POOL_TEST_STALL(k) test_stall(k)
 #include "../cute_nucleotides_amd/csrc/copy_pool.hpp"
 
 #include <cstdio>
 #include <random>
+
+static int run_stall() {
+    const size_t big = (size_t)9 << 20;
+    std::vector<uint8_t> src(big + 4096, 0x11), src2(big + 4096, 0x22);
+    std::vector<uint8_t> old_dst(big + 4096, 0), new_dst(big + 4096, 0);
+    CopyPool pool;
+    pool.copy(new_dst.data(), src.data(), big, false);  // starts the team; helpers are spinning now
+    g_stall_armed.store(1);
+    pool.copy(old_dst.data() + 1, src.data(), big, true);  // job G: fresh-page blocks (2 MiB); helper 1 parks between its field loads
+    for (int i = 0; i < 20000 && !g_stalled.load(); ++i) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (!g_stalled.load()) { printf("note: the helper never reached the stall point (copy finished without it)\n"); }
+    memset(old_dst.data(), 0xEE, old_dst.size());  // the caller owns its buffer again: nothing may write it from here on
+    int bad = 0;
+    for (int round = 0; round < 3; ++round) {
+        memset(new_dst.data(), 0, new_dst.size());
+        pool.copy(new_dst.data() + 3, src2.data(), big, false);  // job G+1: warm blocks (1 MiB): twice the block count
+        if (round == 0) {
+            // the window the advisor describes: the new job's fields are published; let the parked helper go on
+            g_release.store(1);
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+        if (memcmp(new_dst.data() + 3, src2.data(), big) != 0) ++bad;
+    }
+    for (uint8_t b : old_dst) bad += b != 0xEE;
+    return bad;
+}
 
 static int run_thread(unsigned seed, int copies, size_t max_bytes) {
     std::mt19937_64 rng(seed);
@@ -34,6 +78,16 @@ static int run_thread(unsigned seed, int copies, size_t max_bytes) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "stall")) {
+        int bad = 0;
+        for (int i = 0; i < 20; ++i) {
+            g_stall_armed.store(0); g_stalled.store(0); g_release.store(0);
+            bad += run_stall();
+        }
+        if (bad) { printf("FAILED: %d bad bytes\n", bad); return 1; }
+        printf("ok stall\n");
+        return 0;
+    }
     const int copies = argc > 1 ? atoi(argv[1]) : 600, threads = argc > 2 ? atoi(argv[2]) : 3;
     const size_t max_bytes = (size_t)(argc > 3 ? atoi(argv[3]) : 6) << 20;
     std::vector<int> bad(threads, 0);

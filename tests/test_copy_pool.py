@@ -36,3 +36,14 @@ def test_copy_pool_stress_thread_sanitizer(tmp_path):
     if "FATAL: ThreadSanitizer" in r.stderr and "unexpected memory mapping" in r.stderr:
         pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_copy_pool_stalled_helper_cannot_mix_two_jobs(tmp_path):
+    """a helper parked between its loads of a job's fields, across the end of that job and the
+    publication of the next one (different block size), must neither touch the old job's memory nor the new job's
+    completion counter."""
+    exe, err = _build(tmp_path, [])
+    assert exe, err
+    r = subprocess.run([exe, "stall"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok stall" in r.stdout, r.stdout + r.stderr
