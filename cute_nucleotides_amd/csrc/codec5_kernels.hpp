@@ -438,4 +438,107 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------
+// PIPELINED wave tiles (round 4).  The L2 <-> fabric counters (profiles/r04_bound_counters_codec5.json) show both
+// directions IN-FLIGHT starved, not pushed back by the memory side: the encoder keeps 36.6k reads outstanding at the
+// 2-bit encoder's latency (0.93 us) where that one keeps 39.2k, the decoder 12.8k writes where the 2-bit decoder keeps
+// 15.4k, with write-credit stalls at 0.6 % of L2-busy against 5.6 % -- a wave that is staging through LDS and doing
+// base-5 arithmetic has nothing in flight, and that phase is long here.  So one wave takes K CONSECUTIVE tiles and
+// issues tile i+1's global loads BEFORE it touches tile i's data: the arithmetic of a tile runs under the next
+// tile's read latency.  One slab per wave is enough (a wave's LDS instructions execute in issue order: tile i+1's
+// ds_writes cannot pass tile i's ds_reads; the fences only pin the compiler).  Loads return in order, so waiting for
+// tile i's vectors leaves tile i+1's outstanding (vmcnt counts down in issue order; tile i's stores are issued after
+// tile i+1's loads and never gate them).
+// ---------------------------------------------------------------------------
+// Branch-free on purpose: the grid covers whole groups of K tiles only (the launcher hands the < K leftover tiles to the
+// edge words), and the fourth 16-B access of a 3456-B tile -- 24 lanes' worth -- is issued by ALL lanes against a
+// descriptor that ends with the tile: lanes 24..63 fall outside, read zeros / drop their stores without touching memory,
+// and the slab is a full 4 KiB so the LDS side needs no lane mask either.  (With the lane-masked accesses of
+// n_to_bits2_wave the compiler's s_waitcnt insertion lost track across the exec branches and waited for tile i+1's loads
+// before staging tile i -- vmcnt(2..0) where vmcnt(7..4) was meant -- which is the whole point gone.)
+constexpr int kPipeSlabDwords5 = 1024 + 4;  // 4 wave-wide 16-B rows + the 8-dword read-ahead of the last lane
+template <int K, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(64) void n_to_bits2_pipe(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, Encode2Edges e) {
+    constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, NLD = 4;
+    static_assert((kWaveVecs5 * WPL + 63) / 64 == NLD, "four wave-wide rows per tile");
+    __shared__ __attribute__((aligned(16))) uint32_t my[kPipeSlabDwords5];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * K;
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    u32x4 v[K][NLD];
+    auto issue = [&](int k) {
+        const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + (t0 + k) * TILE_BYTES, TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) v[k][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
+    };
+    issue(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k + 1 < K) issue(k + 1);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[k][i];
+        wave_lds_fence();
+        const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + (t0 + k) * (TILE_WORDS * 8), TILE_WORDS * 8);
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const uint64_t word = word_from_slab<STRICT>(my, 27u * lane + (uint32_t)kWaveBytes5 * j);
+            const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
+        }
+        wave_lds_fence();
+    }
+    if (blockIdx.x + e.groups >= gridDim.x)
+        encode2_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - gridDim.x) * 64 + lane, (uint64_t)e.groups * 64);
+}
+
+template <int K, int LAUX, int SAUX>
+__global__ __launch_bounds__(64) void bits_to_n2_pipe(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, Decode2Edges e) {
+    constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, NST = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t my[kPipeSlabDwords5];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * K;
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    vu2 w[K][WPL];
+    auto issue = [&](int k) {
+        const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + (t0 + k) * (TILE_WORDS * 8), TILE_WORDS * 8);
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) w[k][j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
+    };
+    const uint32_t byte0 = 27u * lane, q0 = byte0 >> 2, ph = byte0 & 3u;
+    const uint32_t sel = 0x07060504u - 0x01010101u * ph;
+    const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
+    issue(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k + 1 < K) issue(k + 1);
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            uint32_t b[7];
+            decode27(w[k][j][0], w[k][j][1], b);
+            uint32_t W[8];
+            W[0] = __builtin_amdgcn_perm(b[0], 0u, sel);
+#pragma unroll
+            for (int q = 1; q < 7; ++q) W[q] = __builtin_amdgcn_perm(b[q], b[q - 1], sel);
+            W[7] = __builtin_amdgcn_perm(0u, b[6], sel);
+            const uint32_t tail = cnt == 6 ? W[6] : W[7];
+            const uint32_t prev_tail = __shfl_up(tail, 1, 64);
+            if (ph != 0) W[0] |= prev_tail;
+            uint32_t* dst = my + kWaveDwords5 * j + q0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dst[q] = W[q];
+            if (cnt == 7) dst[6] = W[6];
+        }
+        wave_lds_fence();
+        const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + (t0 + k) * TILE_BYTES, TILE_BYTES);  // lanes 24..63 of the 4th store fall outside: dropped
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(my + (i * 64 + lane) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
+        }
+        wave_lds_fence();
+    }
+    if (blockIdx.x + e.groups >= gridDim.x)
+        decode2_edges(e, (uint64_t)(blockIdx.x + e.groups - gridDim.x) * 64 + lane, (uint64_t)e.groups * 64);
+}
+
 }  // namespace cnt

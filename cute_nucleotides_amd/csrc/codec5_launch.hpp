@@ -44,7 +44,26 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=sc1|nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},     // 25
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=plain st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},      // 26
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc0|sc1|nt, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 27
+    // round 4: pipelined -- one wave takes K consecutive tiles and loads tile i+1 before it touches tile i (codec5_kernels.hpp)
+    {"pipelined K=2, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 28
+    {"pipelined K=2, ld=nt st=sc1, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 29
+    {"pipelined K=2, ld=nt st=sc1, 10 wg/CU", 2 * kWaveBytes5, 64, 10},  // 30
+    {"pipelined K=4, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 31
+    {"pipelined K=4, ld=nt st=sc1, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 32
+    {"pipelined K=4, ld=nt st=sc1, 10 wg/CU", 2 * kWaveBytes5, 64, 10},  // 33
+    {"pipelined K=8, ld=nt st=sc1, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 34
+    {"pipelined K=8, ld=nt st=sc1, 8 wg/CU", 2 * kWaveBytes5, 64, 8},    // 35
+    {"pipelined K=2, ld=nt st=sc1, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 36
+    {"pipelined K=4, ld=nt st=sc0|sc1|nt, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 37
+    // multi-wave workgroups were only ever measured uncapped (variants 2, 3): four waves = 4 KiB of packed output per workgroup
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1, 3 wg/CU", 2 * kWaveBytes5, 64, 3},  // 38
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1, 4 wg/CU", 2 * kWaveBytes5, 64, 4},  // 39
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1, 5 wg/CU", 2 * kWaveBytes5, 64, 5},  // 40
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1, 7 wg/CU", 2 * kWaveBytes5, 64, 7},  // 41
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1, 8 wg/CU", 2 * kWaveBytes5, 64, 8},  // 42
 };
+inline int encode2_waves(int variant) { return variant == 3 || (variant >= 38 && variant <= 40) ? 4 : variant == 2 || variant == 41 || variant == 42 ? 2 : 1; }
+inline int encode2_pipe_k(int variant) { return variant == 28 || variant == 29 || variant == 30 || variant == 36 ? 2 : variant == 34 || variant == 35 ? 8 : (variant >= 31 && variant <= 37) ? 4 : 0; }
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
@@ -80,7 +99,25 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},   // 29
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=nt st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 30
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=sc1 st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16}, // 31
+    // round 4: pipelined -- one wave takes K consecutive tiles and loads tile i+1's words before it expands tile i
+    {"pipelined K=2, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 32
+    {"pipelined K=2, ld=plain st=sc0|sc1|nt, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 33
+    {"pipelined K=4, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 34
+    {"pipelined K=4, ld=plain st=sc0|sc1|nt, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 35
+    {"pipelined K=4, ld=plain st=sc0|sc1|nt, 10 wg/CU", 2 * kWaveBytes5, 64, 10},  // 36
+    {"pipelined K=8, ld=plain st=sc0|sc1|nt, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 37
+    {"pipelined K=8, ld=plain st=sc0|sc1|nt, 8 wg/CU", 2 * kWaveBytes5, 64, 8},    // 38
+    {"pipelined K=2, ld=plain st=sc0|sc1|nt, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 39
+    {"pipelined K=4, ld=plain st=sc0|sc1|nt, 20 wg/CU", 2 * kWaveBytes5, 64, 20},  // 40
+    // four waves = one 4-KiB page of packed input per workgroup, under a residency cap for the first time
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt, 3 wg/CU", 2 * kWaveBytes5, 64, 3},  // 41
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt, 4 wg/CU", 2 * kWaveBytes5, 64, 4},  // 42
+    {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt, 5 wg/CU", 2 * kWaveBytes5, 64, 5},  // 43
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt, 7 wg/CU", 2 * kWaveBytes5, 64, 7},  // 44
+    {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt, 8 wg/CU", 2 * kWaveBytes5, 64, 8},  // 45
 };
+inline int decode2_waves(int variant) { return variant == 3 || (variant >= 41 && variant <= 43) ? 4 : variant == 2 || variant == 44 || variant == 45 ? 2 : 1; }
+inline int decode2_pipe_k(int variant) { return variant == 32 || variant == 33 || variant == 39 ? 2 : variant == 37 || variant == 38 ? 8 : (variant >= 34 && variant <= 40) ? 4 : 0; }
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
 // Whole wave tiles of [d_n, d_n + n_len) plus -- for the one-wave variants, in the same (last) launch -- the edge words `e`
@@ -90,12 +127,13 @@ template <bool STRICT>
 int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, Encode2Edges e, hipStream_t s, uint64_t* done_words, bool* edges_done) {
     if (variant < 0 || variant >= kNumEncode2Variants) return 1;
     const uint64_t tile_nt = kEncode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
-    const uint64_t total = n_len / tile_nt;
+    const int pk = encode2_pipe_k(variant);
+    const uint64_t total = pk ? n_len / tile_nt / pk * pk : n_len / tile_nt;  // pipelined: whole groups of K tiles, the rest are edge words
     *done_words = total * tile_words;
-    const bool one_wave = variant != 2 && variant != 3;
+    const bool one_wave = encode2_waves(variant) == 1;
     *edges_done = one_wave && total > 0;
     e.tail_first = e.head_words + *done_words;
-    const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;  // wave tiles per launch (<= 2^31-1 threads)
+    const uint64_t per_launch = max_tiles_per_launch(64) / 8 * 8;  // wave tiles per launch (<= 2^31-1 threads; whole pipeline groups)
     const uint32_t xs = xcd_shift();
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
@@ -103,15 +141,26 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_words * 8;
         e.groups = (one_wave && first + n == total) ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         // the static slab is 3488 B (2 words per lane) / 6944 B (4 words per lane), allocated in 512-B granules
-        const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;
+        const uint32_t slab = encode2_waves(variant) == 4 ? 14336u : encode2_waves(variant) == 2 || tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;
         const uint32_t lds = lds_pad_for_cap(kEncode2Variants[variant].wg_cap, slab);
 #define CNT_ENC2(W, P, L, S) \
     hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
+#define CNT_ENC2P(K, L, S) \
+    hipLaunchKernelGGL((n_to_bits2_pipe<K, L, S, STRICT>), dim3(grid_of(n / K)), dim3(64), lds, s, in, out, e)
+        if (pk) {
+            e.groups = first + n == total ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n / pk) : 0u;
+            const uint32_t lds = lds_pad_for_cap(kEncode2Variants[variant].wg_cap, 4608u);  // the pipelined slab is a full 4 KiB (+16 B)
+            if (variant == 37) CNT_ENC2P(4, kNT, kSC0 | kSC1 | kNT);
+            else if (pk == 2) CNT_ENC2P(2, kNT, kSC1);
+            else if (pk == 4) CNT_ENC2P(4, kNT, kSC1);
+            else CNT_ENC2P(8, kNT, kSC1);
+            continue;
+        }
         switch (variant) {
             case 0: CNT_ENC2(1, 2, kNT, kSC1); break;
             case 1: CNT_ENC2(1, 4, kNT, kSC1); break;
-            case 2: CNT_ENC2(2, 2, kNT, kSC1); break;
-            case 3: CNT_ENC2(4, 2, kNT, kSC1); break;
+            case 2: case 41: case 42: CNT_ENC2(2, 2, kNT, kSC1); break;
+            case 3: case 38: case 39: case 40: CNT_ENC2(4, 2, kNT, kSC1); break;
             case 4: CNT_ENC2(1, 1, kNT, kSC1); break;
             case 5: CNT_ENC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: case 11: case 12: case 13: case 14: case 15: CNT_ENC2(1, 2, kNT, kSC1); break;
@@ -127,6 +176,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
             default: return 1;
         }
 #undef CNT_ENC2
+#undef CNT_ENC2P
     }
     return 0;
 }
@@ -152,12 +202,13 @@ void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, ui
 inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t len, Decode2Edges e, hipStream_t s, uint64_t* done_words, bool* edges_done) {
     if (variant < 0 || variant >= kNumDecode2Variants) return 1;
     const uint64_t tile_nt = kDecode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
-    const uint64_t total = len / tile_nt;
+    const int pk = decode2_pipe_k(variant);
+    const uint64_t total = pk ? len / tile_nt / pk * pk : len / tile_nt;
     *done_words = total * tile_words;
-    const bool one_wave = variant != 2 && variant != 3;
+    const bool one_wave = decode2_waves(variant) == 1;
     *edges_done = one_wave && total > 0;
     e.tail_first = e.head_words + *done_words;
-    const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
+    const uint64_t per_launch = max_tiles_per_launch(64) / 8 * 8;
     const uint32_t xs = xcd_shift();
     constexpr int kAll = kSC0 | kSC1 | kNT;
     for (uint64_t first = 0; first < total; first += per_launch) {
@@ -165,16 +216,26 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         const uint8_t* in = static_cast<const uint8_t*>(d_bits) + first * tile_words * 8;
         uint8_t* out = static_cast<uint8_t*>(d_out) + first * tile_nt;
         e.groups = (one_wave && first + n == total) ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
-        const uint32_t slab = tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;  // static slab, see launch_encode2
+        const uint32_t slab = decode2_waves(variant) == 4 ? 14336u : decode2_waves(variant) == 2 || tile_nt == 4 * kWaveBytes5 ? 7168u : 3584u;  // static slab, see launch_encode2
         const uint32_t lds = lds_pad_for_cap(kDecode2Variants[variant].wg_cap, slab);
 #define CNT_DEC2(W, P, L, S) \
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
+#define CNT_DEC2P(K) \
+    hipLaunchKernelGGL((bits_to_n2_pipe<K, 0, kAll>), dim3(grid_of(n / K)), dim3(64), lds, s, in, out, e)
+        if (pk) {
+            e.groups = first + n == total ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n / pk) : 0u;
+            const uint32_t lds = lds_pad_for_cap(kDecode2Variants[variant].wg_cap, 4608u);
+            if (pk == 2) CNT_DEC2P(2);
+            else if (pk == 4) CNT_DEC2P(4);
+            else CNT_DEC2P(8);
+            continue;
+        }
         switch (variant) {
             case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
-            case 2: CNT_DEC2(2, 2, 0, kAll); break;
-            case 3: CNT_DEC2(4, 2, 0, kAll); break;
+            case 2: case 44: case 45: CNT_DEC2(2, 2, 0, kAll); break;
+            case 3: case 41: case 42: case 43: CNT_DEC2(4, 2, 0, kAll); break;
             case 4: CNT_DEC2(1, 1, 0, kAll); break;
             case 5: CNT_DEC2(1, 2, 0, 0); break;
             case 6: case 7: case 8: CNT_DEC2(1, 2, 0, kAll); break;
@@ -188,6 +249,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             default: return 1;
         }
 #undef CNT_DEC2
+#undef CNT_DEC2P
     }
     return 0;
 }
