@@ -11,8 +11,9 @@ generator, seed in the JSON) and are resident in HBM before the timed region sta
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W          (N>1, one rank per GPU: the driver's form)
     python bench.py --gpus N --steps K --warmup W                       (N>1 WITHOUT a launcher: ONE process drives the
-        N devices through cnt_n_to_bits_sharded_dev / cnt_bits_to_n_sharded_dev -- one library-owned stream per device,
-        no process group at all -- and prints the same JSON line; what north_star describes)
+        N devices through the enqueue-only sharded tier -- cnt_*_sharded_dev_enqueue queues all K steps on one library
+        stream per shard, ONE cnt_sharded_dev_wait; no process group at all -- and prints the same JSON line plus
+        `scaling_overhead_us`; what north_star describes; bench/bench_single_process.py)
 
 N>1: the global buffer (N x per-GPU size) is cut into contiguous chunks on word boundaries,
 rank r owns chunk r (cute_nucleotides_amd/sharding.py); there is no data-path collective --
@@ -46,13 +47,16 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for _p in (ROOT, os.path.join(ROOT, "bench")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
-HOST_TIER_LOG2 = (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)  # sizes of the host-tier / one-CPU-thread crossover table
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_PER_NT = 1.25    # algorithmic bytes per nucleotide, each direction
-
+# Everything that is not the contract itself lives in bench/ (VERDICT r03 next-8): bench_measure.py = statistics, HIP-event
+# timing loops and the extra blocks of the N = 1 line; bench_single_process.py = `--gpus N` without a launcher.  This file
+# keeps the arguments, the CPU-baseline leg (the only code allowed to touch oracle/), the timed region and the JSON line.
+from bench_measure import (BYTES_PER_NT, HBM_PEAK_GBS, HOST_TIER_LOG2, crossover, gbs, gpu_numa_node, host_placement,  # noqa: E402,F401
+                           load_probes, measure_ceilings, measure_codec5, measure_host_tier, measure_packed_ops, measure_pcie,
+                           measure_traffic_live, numpy_pack, physical_cores, sockets, stats_ms, timed_calls, timed_queued)
 
 def parse_args():
     p = argparse.ArgumentParser()
@@ -67,26 +71,6 @@ def parse_args():
     p.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs; quote profiles/hbm_traffic.json")
     p.add_argument("--shard-log2-nt", type=int, default=35, help="per-GPU shard of BASELINE.json configs[4] (256 GiB over 8 GPUs = 2^35 nt each)")
     return p.parse_args()
-
-
-def physical_cores(cpus):
-    """distinct (package, core) pairs among the CPUs this process may run on"""
-    seen = set()
-    for c in cpus:
-        try:
-            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
-            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
-        except OSError:
-            return None
-    return len(seen)
-
-
-def sockets():
-    try:
-        return len({open(os.path.join(d, "topology", "physical_package_id")).read().strip()
-                    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*") if os.path.exists(os.path.join(d, "topology"))})
-    except OSError:
-        return None
 
 
 def cpu_baseline(seconds):
@@ -233,574 +217,6 @@ def cpu_baseline(seconds):
     }
 
 
-def stats_ms(ms):
-    """mean / median / min / max and, from 10 samples on, p10 / p90 (decode's launches spread 3-9 % on one box with the
-    clock flat: profiles/r04_decode_spread.md -- a mean alone hides that)"""
-    s = sorted(ms)
-    out = {"mean": round(statistics.fmean(ms), 4), "median": round(statistics.median(ms), 4), "min": round(s[0], 4),
-           "max": round(s[-1], 4), "n": len(ms)}
-    if len(s) >= 10:
-        out["p10"], out["p90"] = round(s[len(s) // 10], 4), round(s[(9 * len(s)) // 10], 4)
-    return out
-
-
-def gbs(nbytes, ms):
-    return nbytes / (ms * 1e-3) / 1e9
-
-
-def timed_calls(torch, fn, iters, warm=1):
-    """[ms] of `iters` individual fn() calls, each between two HIP events on torch's current stream (the stream
-    the C ABI is handed)."""
-    for _ in range(warm):
-        fn()
-    out = []
-    for _ in range(iters):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
-        e1.synchronize()
-        out.append(e0.elapsed_time(e1))
-    return out
-
-
-def timed_queued(torch, fn, reps, queue, warm=1):
-    """[ms per call] of `reps` measurements, each `queue` back-to-back fn() calls between ONE pair of HIP events: the
-    average launch duration with the launches queued behind each other, as in the timed region of the headline (and
-    as rocprofv3's kernel trace sees them).  A single call between two events also counts the 10-50 us the host needs
-    to get from the event record to the launch -- 5 % of a 0.2 ms kernel at the 1 GiB configs."""
-    for _ in range(warm):
-        fn()
-    out = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(queue):
-            fn()
-        e1.record()
-        e1.synchronize()
-        out.append(e0.elapsed_time(e1) / queue)
-    return out
-
-
-def numpy_pack(n):
-    """(byte>>1)&3, 32 codes per u64, LSB first (n_to_bits.rs:38-43, :85) -- three lines of numpy for the sampled
-    check of the TIMED packed buffer; bench.py touches oracle/ only in cpu_baseline()"""
-    import numpy as np
-
-    c = ((n >> 1) & 3).astype(np.uint64).reshape(-1, 32)
-    return (c << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
-
-
-def load_probes():
-    """bench/libcnt_probes.so (built by __graft_entry__.build(), travels with the snapshot): no-arithmetic streams
-    issued like the shipped kernels, for the same-run ceilings.  None if it is not there."""
-    path = os.path.join(ROOT, "bench", "libcnt_probes.so")
-    if not os.path.exists(path):
-        return None
-    P = ctypes.CDLL(path)
-    P.probe_shipped.restype = ctypes.c_int
-    P.probe_shipped.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-    return P
-
-
-def measure_ceilings(torch, P, d_a, d_b, nbytes, iters=5):
-    """TB/s (decimal) of the five no-arithmetic streams over the headline's own buffers: d_a is only read, d_b is
-    overwritten (call after verification).  nbytes = the 16-B-per-lane side (the ASCII side of the codec)."""
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rows = {}
-    for name, kind, moved in (("read_only", 0, nbytes), ("write_only", 4, nbytes), ("copy_1to1", 1, 2 * nbytes),
-                              ("read4_write1_encode_shape", 2, 1.25 * nbytes), ("read1_write4_decode_shape", 3, 1.25 * nbytes)):
-        def call():
-            rc = P.probe_shipped(kind, d_a.data_ptr(), d_b.data_ptr(), nbytes, stream)
-            if rc:
-                raise RuntimeError("probe_shipped(%d) -> %d" % (kind, rc))
-        ms = timed_calls(torch, call, iters)
-        rows[name] = {"GBs": round(gbs(moved, statistics.median(ms)), 1), "best_GBs": round(gbs(moved, min(ms)), 1),
-                      "bytes_moved": int(moved), "ms_median": round(statistics.median(ms), 4)}
-    return rows
-
-
-def measure_codec5(torch, seed, log2_nt, reps=4, queue=4):
-    """SURVEY 8 f-1 on the driver line: the 5-letter codec (n_to_bits2 / bits_to_n2, n_to_bits2.rs:37-107) at the metric's
-    size on device-resident random ACGTN.  Algorithmic bytes per nucleotide 1 + 8/27 in each direction (27 nt per u64).
-    Verified in-run: the reference's own vector ("ATCGN" x 7, n_to_bits2.rs:276-277) through the same device entry
-    points, and decode(encode(x)) == x over the whole timed buffer."""
-    import numpy as np
-
-    import cute_nucleotides_amd as cn
-    from cute_nucleotides_amd import devutil
-
-    n = 1 << log2_nt
-    words = (n + 26) // 27
-    dev = torch.device("cuda", torch.cuda.current_device())
-    d = torch.empty(n, dtype=torch.uint8, device=dev)
-    packed = torch.empty(words, dtype=torch.int64, device=dev)
-    back = torch.empty(n, dtype=torch.uint8, device=dev)
-    devutil.fill_random_acgtn(d, seed + 5)
-    enc = lambda: cn.n_to_bits2_dev(d, out=packed)
-    dec = lambda: cn.bits_to_n2_dev(packed, n, out=back)
-    e, dd = timed_queued(torch, enc, reps, queue, warm=1), timed_queued(torch, dec, reps, queue, warm=1)
-    ok = devutil.count_mismatch(d, back) == 0
-    kat = torch.from_numpy(np.frombuffer(b"ATCGN" * 7, dtype=np.uint8).copy()).to(dev)
-    kb = cn.n_to_bits2_dev(kat)
-    ok = ok and [int(x) & 0xFFFFFFFFFFFFFFFF for x in kb.cpu().tolist()] == [0x36A45D1F46D48BA3, 0x5D1F4]
-    ok = ok and bool(torch.equal(cn.bits_to_n2_dev(kb, 35), kat))
-    bpn = 1.0 + 8.0 / 27.0
-    row = lambda ms: {"ms": stats_ms(ms), "gnts": round(n / (statistics.median(ms) * 1e-3) / 1e9, 1),
-                      "achieved_GBs": round(gbs(bpn * n, statistics.median(ms)), 1), "frac": round(gbs(bpn * n, statistics.median(ms)) / HBM_PEAK_GBS, 4)}
-    out = {"what": "5-letter codec {A,C,G,T/U,N} (n_to_bits2.rs): 3 nt -> a + 5b + 25c, 27 nt per u64; device tier, 2^%d nt of random ACGTN "
-                   "(P(N) = 1/16), %d launches queued per HIP-event pair" % (log2_nt, queue),
-           "nt": n, "algorithmic_bytes_per_nt": round(bpn, 4), "encode": row(e), "decode": row(dd), "verified": bool(ok),
-           "encode_kernel": dict(devutil.variants("encode2"))[devutil.get_tuning("encode2")],
-           "decode_kernel": dict(devutil.variants("decode2"))[devutil.get_tuning("decode2")]}
-    del d, packed, back
-    torch.cuda.empty_cache()
-    return out
-
-
-def measure_packed_ops(torch, seed, log2_nt, reps=4, queue=5):
-    """SURVEY 8 f-4 on the driver line: the packed-domain operations at the metric's size (README.md:20-25,45 names them,
-    the reference does not implement them: parity unpinned by construction).  Algorithmic bytes per nucleotide: hamming
-    2 x 0.25 read, complement / reverse complement 0.25 read + 0.25 written, validate 1 read.  Verified in-run by
-    algebraic properties over the whole buffers: two independent uniform sequences differ in 3/4 of the positions,
-    hamming(x, complement(x)) == len, both complements are involutions, a generated ACGT buffer validates clean."""
-    import cute_nucleotides_amd as cn
-    from cute_nucleotides_amd import devutil, packed_ops as po
-
-    n = 1 << log2_nt
-    dev = torch.device("cuda", torch.cuda.current_device())
-    d = torch.empty(n, dtype=torch.uint8, device=dev)
-    devutil.fill_random_acgt(d, seed + 6)
-    x = cn.n_to_bits_dev(d)
-    devutil.fill_random_acgt(d, seed + 7)
-    y = cn.n_to_bits_dev(d)
-    out = torch.empty_like(x)
-    acc = torch.zeros(1, dtype=torch.int64, device=dev)  # the reductions ADD to a caller-owned counter: nothing but their kernel is timed
-    ops = (("hamming", 0.5, lambda: po.hamming_dev(x, y, n, acc=acc)),
-           ("complement", 0.5, lambda: po.complement_dev(x, n, out=out)),
-           ("reverse_complement", 0.5, lambda: po.reverse_complement_dev(x, n, out=out)),
-           ("validate", 1.0, lambda: po.validate_dev(d, acc=acc)))
-    rows = {}
-    for name, bpn, fn in ops:
-        ms = timed_queued(torch, fn, reps, queue, warm=1)
-        med = statistics.median(ms)
-        rows[name] = {"ms": stats_ms(ms), "bytes_per_nt": bpn, "gnts": round(n / (med * 1e-3) / 1e9, 1),
-                      "achieved_GBs": round(gbs(bpn * n, med), 1), "frac": round(gbs(bpn * n, med) / HBM_PEAK_GBS, 4)}
-    dist = int(po.hamming_dev(x, y, n).item())
-    ok = abs(dist / n - 0.75) < 1e-3
-    comp = po.complement_dev(x, n)
-    ok = ok and int(po.hamming_dev(x, comp, n).item()) == n
-    ok = ok and bool(torch.equal(po.complement_dev(comp, n), x))
-    del comp
-    rc = po.reverse_complement_dev(x, n)
-    ok = ok and bool(torch.equal(po.reverse_complement_dev(rc, n), x))
-    del rc
-    ok = ok and int(po.validate_dev(d).item()) == 0
-    rows.update({"what": "packed-domain operations on 2-bit words without decoding; device tier, 2^%d nt, %d calls queued per HIP-event pair"
-                         % (log2_nt, queue), "nt": n, "verified": bool(ok), "parity": "unpinned (no reference vectors exist); property checks in-run"})
-    del d, x, y, out
-    torch.cuda.empty_cache()
-    return rows
-
-
-def measure_pcie(torch, nbytes=1 << 30, reps=5):
-    """Same-run PCIe ceilings for the host tier: hipMemcpy between PINNED host memory and the device, both directions,
-    GiB/s -- what a transfer-bound host-pointer call could reach with free staging."""
-    dev = torch.device("cuda", torch.cuda.current_device())
-    h = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-    d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    h.zero_()
-    out = {}
-    for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
-        ms = timed_calls(torch, fn, reps, warm=1)
-        out[name + "_GiBs"] = round(nbytes / (statistics.median(ms) * 1e-3) / 2**30, 2)
-    del h, d
-    return out
-
-
-def measure_host_tier(seed):
-    """The drop-in host-pointer tier (cnt_n_to_bits / cnt_bits_to_n: H2D + kernel + D2H inside, PCIe-bound) at the
-    sizes of the crossover table, timed like the reference's harness times its functions: one calling thread, the
-    output allocated inside every timed call (np.empty -> fresh pages, like a fresh Vec), and again into a reused
-    output.  GiB/s of nucleotides.  Never part of `value`."""
-    import numpy as np
-
-    from cute_nucleotides_amd import _lib
-
-    L = _lib.lib()
-    rng = np.random.default_rng(seed)
-    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 1 << HOST_TIER_LOG2[-1], dtype=np.uint8)]
-    rows = {}
-    for log2 in HOST_TIER_LOG2:
-        m = 1 << log2
-        n = big[:m]
-        words = m // 32
-        bits = np.empty(words, dtype=np.uint64)
-        back = np.empty(m, dtype=np.uint8)
-        p = lambda a: ctypes.c_void_p(a.ctypes.data)
-
-        def enc_fresh():
-            out = np.empty(words, dtype=np.uint64)
-            return L.cnt_n_to_bits(p(n), m, p(out), words)
-
-        def dec_fresh():
-            out = np.empty(m, dtype=np.uint8)
-            return L.cnt_bits_to_n(p(bits), words, m, p(out))
-
-        kept = []  # "dropped later": the result outlives the call and is freed outside the timed loop (criterion's iter_with_large_drop)
-
-        def enc_fresh_kept():
-            out = np.empty(words, dtype=np.uint64)
-            kept.append(out)
-            return L.cnt_n_to_bits(p(n), m, p(out), words)
-
-        def dec_fresh_kept():
-            out = np.empty(m, dtype=np.uint8)
-            kept.append(out)
-            return L.cnt_bits_to_n(p(bits), words, m, p(out))
-
-        def enc_reuse():
-            return L.cnt_n_to_bits(p(n), m, p(bits), words)
-
-        def dec_reuse():
-            return L.cnt_bits_to_n(p(bits), words, m, p(back))
-
-        row = {}
-        for name, fn in (("n_to_bits_hip reused out", enc_reuse), ("bits_to_n_hip reused out", dec_reuse),
-                         ("n_to_bits_hip fresh out", enc_fresh), ("bits_to_n_hip fresh out", dec_fresh)):
-            assert fn() == 0
-            t0, k = time.perf_counter(), 0
-            while True:
-                fn()
-                k += 1
-                dt = time.perf_counter() - t0
-                if dt > 0.12 or k >= 20000:
-                    break
-            row[name] = round(m / (dt / k) / 2**30, 3)
-            row[name + " us"] = round(dt / k * 1e6, 2)
-        if log2 >= 26:  # large outputs: the same fresh-output calls with the DROP of the result outside the timed loop
-            for name, fn in (("n_to_bits_hip fresh out, dropped later", enc_fresh_kept), ("bits_to_n_hip fresh out, dropped later", dec_fresh_kept)):
-                reps = 3 if log2 >= 30 else 6
-                fn()
-                kept.clear()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    fn()
-                dt = time.perf_counter() - t0
-                kept.clear()
-                row[name + " us"] = round(dt / reps * 1e6, 2)
-        assert np.array_equal(back, n)
-        rows["2^%d" % log2] = row
-    rows["placement"] = {"input": host_placement(big), "reused_output": host_placement(back)}
-    return rows
-
-
-def host_placement(arr):
-    """Where a host array's pages lie (NUMA nodes, share in transparent huge pages) and which CPU the caller is on: the host
-    tier's 1-GiB rows move by 15 % with these (profiles/r03_host_numa_placement.jsonl), so the line says what it ran on."""
-    out = {}
-    try:
-        addr = arr.ctypes.data + arr.nbytes // 2  # the middle: an madvise'd array is several mappings (numpy advises its interior)
-        start = None
-        for line in open("/proc/self/maps"):
-            lo, hi = (int(x, 16) for x in line.split()[0].split("-"))
-            if lo <= addr < hi:
-                start = lo
-                break
-        if start is not None:
-            for line in open("/proc/self/numa_maps"):
-                f = line.split()
-                if int(f[0], 16) == start:
-                    out["pages_per_node"] = {x.split("=")[0]: int(x.split("=")[1]) for x in f[2:] if x[0] == "N" and x[1:2].isdigit()}
-                    break
-            want, size, huge = "%x-" % start, None, None
-            hit = False
-            for line in open("/proc/self/smaps"):
-                if line.startswith(want):
-                    hit = True
-                elif hit and line.startswith("Size:"):
-                    size = int(line.split()[1])
-                elif hit and line.startswith("AnonHugePages:"):
-                    huge = int(line.split()[1])
-                    break
-            if size:
-                out["huge_page_share"] = round(huge / size, 3)
-        cpu = ctypes.CDLL(None).sched_getcpu()
-        node = [d for d in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu) if d.startswith("node")]
-        out["caller_cpu"] = cpu
-        out["caller_node"] = node[0] if node else None
-    except (OSError, ValueError, AttributeError, IndexError):
-        pass
-    return out
-
-
-def gpu_numa_node(bdf):
-    try:
-        return int(open("/sys/bus/pci/devices/%s/numa_node" % str(bdf).lower()).read())
-    except (OSError, ValueError):
-        return None
-
-
-def crossover(host_rows, cpu_rows):
-    """smallest table size from which the host tier stays ahead of ONE CPU thread running the reference's fastest
-    AVX2 path, both allocating their output inside the call (the reference's bench rule)"""
-    out = {}
-    for gpu_key, cpu_key in (("n_to_bits_hip fresh out", "n_to_bits_movemask"), ("bits_to_n_hip fresh out", "bits_to_n_shuffle")):
-        sizes = [k for k in host_rows if k in cpu_rows and cpu_key in cpu_rows[k]]
-        ahead = [host_rows[k][gpu_key] > cpu_rows[k][cpu_key] for k in sizes]
-        first = next((sizes[i] for i in range(len(sizes)) if all(ahead[i:])), None)
-        out[gpu_key.split()[0] + " vs " + cpu_key] = {
-            "host_tier_ahead_from": first,
-            "table_GiBs": {k: [host_rows[k][gpu_key], cpu_rows[k][cpu_key]] for k in sizes},
-            "columns": ["host tier (PCIe inside)", "one CPU thread, " + cpu_key]}
-    return out
-
-
-def measure_traffic_live(log2_nt, timeout_s=90):
-    """HBM bytes per launch of the two timed kernels, measured by THIS run on THIS box: two child processes of
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has 4 counter slots,
-    3 + 2 do not fit; counters are never combined with any other tracing domain) over bench/pmc_workload.py
-    --codec-only, i.e. a read-only and a write-only probe of known size for the calibration (gfx950 reports half of
-    wide coalesced reads, MI355X_MICROARCH.md section HBM) followed by the encode and decode kernels at the same
-    size as the headline.  Returns the summary of bench/parse_profiles.py:traffic_summary, or {"error": ...}."""
-    import shutil
-    import subprocess
-    import tempfile
-
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return {"error": "rocprofv3 not found"}
-    sys.path.insert(0, os.path.join(ROOT, "bench"))
-    import parse_profiles
-
-    tmp = tempfile.mkdtemp(prefix="cnt_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
-    try:
-        csvs = {}
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
-                   sys.executable, os.path.join(ROOT, "bench", "pmc_workload.py"), "--log2-nt", str(log2_nt), "--reps", "2", "--codec-only"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
-            csvs[counter] = os.path.join(out, "pmc_counter_collection.csv")
-            if r.returncode != 0 or not os.path.exists(csvs[counter]):
-                return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout[-300:])}
-        return parse_profiles.traffic_summary(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], 1 << log2_nt, "live")
-    except Exception as exc:  # noqa: BLE001 -- the headline must not die with its evidence leg
-        return {"error": "%s: %s" % (type(exc).__name__, exc)}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-def main_single_process(args):
-    """`python bench.py --gpus N` with N > 1 and NO launcher: this one process drives all N devices through the C ABI's
-    device-resident sharded tier -- shard k of the global buffer lives on device k, cnt_n_to_bits_sharded_dev /
-    cnt_bits_to_n_sharded_dev enqueue every shard on a library-owned stream of its device and return when all devices
-    have finished.  No process group, no collective, no host staging: exactly north_star's "shards trivially by
-    contiguous chunk across the 8 GPUs of one node".  Same JSON line as the one-process-per-GPU form (per-device rows
-    in `ranks`, per-shard kernel times from HIP events on each device's stream, wall clock around the K steps)."""
-    import numpy as np
-    import torch
-
-    import cute_nucleotides_amd as cn
-    from cute_nucleotides_amd import _lib, devutil, sharding
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    N = args.gpus
-    visible = torch.cuda.device_count()
-    shared_gpu = os.environ.get("CNT_BENCH_SHARE_GPU") == "1"  # test support, never set by the driver: fold N shards onto the visible devices
-    if visible < N:
-        if not shared_gpu:
-            raise SystemExit("--gpus %d: only %d HIP device(s) visible to this process (one process drives all N devices; "
-                             "a torch.distributed.run launch with %d ranks works too)" % (N, visible, N))
-        sharding.alias_devices(True)
-    L = _lib.lib()
-    n_per = 1 << args.log2_nt
-    n_global = n_per * N
-    parts = [sharding.shard_range_c(n_global, N, k) for k in range(N)]  # cnt_shard_range: contiguous chunks on word boundaries
-    assert parts == sharding.partition(n_global, N)
-    devs = [torch.device("cuda", k % visible) for k in range(N)]
-
-    def sync_all():
-        for i in range(min(N, visible)):
-            torch.cuda.synchronize(i)
-
-    def arrays(tensors):
-        return (ctypes.c_void_p * N)(*[t.data_ptr() for t in tensors])
-
-    def sizes(values):
-        return (ctypes.c_size_t * N)(*values)
-
-    def run_encode(ins, lens, outs, words, ms=None):
-        _lib.check(L.cnt_n_to_bits_sharded_dev(ins, lens, outs, words, N, 0, ms))
-
-    def run_decode(pks, words, lens, outs, ms=None):
-        _lib.check(L.cnt_bits_to_n_sharded_dev(pks, words, lens, outs, N, 0, ms))
-
-    lens_l = [hi - lo for lo, hi in parts]
-    words_l = [cn.n_to_bits.words_for(x) for x in lens_l]
-    d_in = [torch.empty(x, dtype=torch.uint8, device=d) for x, d in zip(lens_l, devs)]
-    d_pk = [torch.empty(w, dtype=torch.int64, device=d) for w, d in zip(words_l, devs)]
-    d_out = [torch.empty(x, dtype=torch.uint8, device=d) for x, d in zip(lens_l, devs)]
-    for t, (lo, _) in zip(d_in, parts):
-        devutil.fill_random_acgt(t, args.seed, first_nt=lo)
-    sync_all()
-    a_in, a_pk, a_out, a_len, a_words = arrays(d_in), arrays(d_pk), arrays(d_out), sizes(lens_l), sizes(words_l)
-
-    for _ in range(args.warmup):
-        run_encode(a_in, a_len, a_pk, a_words)
-        run_decode(a_pk, a_words, a_len, a_out)
-    ms_e = [(ctypes.c_float * N)() for _ in range(args.steps)]
-    ms_d = [(ctypes.c_float * N)() for _ in range(args.steps)]
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        run_encode(a_in, a_len, a_pk, a_words, ms_e[k])  # returns when every device has finished its shard
-        run_decode(a_pk, a_words, a_len, a_out, ms_d[k])
-    sync_all()
-    elapsed = time.perf_counter() - t0
-
-    verified = None
-    if not args.no_verify:
-        ok = all(devutil.count_mismatch(a, b) == 0 for a, b in zip(d_in, d_out))
-        m = min(1 << 20, lens_l[0] // 32 * 32)
-        for k in (0, N - 1):  # first and last 2^20 nt of the job against the numpy restatement of the layout
-            off = 0 if k == 0 else (lens_l[k] - m) // 32 * 32
-            host_n = d_in[k][off : off + m].cpu().numpy()
-            got = d_pk[k][off // 32 : (off + m) // 32].cpu().numpy().view(np.uint64)
-            ok = ok and bool(np.array_equal(got, numpy_pack(host_n)))
-        kat = torch.from_numpy(np.frombuffer(b"ATCG" * (1 << 18), dtype=np.uint8).copy()).to(devs[0])
-        kat_bits = cn.n_to_bits_dev(kat)
-        ok = ok and bool((kat_bits.cpu().numpy().view(np.uint64) == np.uint64(0xD8D8D8D8D8D8D8D8)).all())
-        verified = bool(ok)
-        del kat, kat_bits
-
-    # ---- BASELINE.json configs[4]: 2^35 nt per GPU through the same entry point -----------------------------------------
-    del d_out, d_pk, d_in, a_in, a_pk, a_out
-    for i in range(min(N, visible)):
-        with torch.cuda.device(i):
-            torch.cuda.empty_cache()
-    shard_rows, shard_wall = [None] * N, None
-    if not args.no_extras and args.shard_log2_nt > 0:
-        s_len = 1 << args.shard_log2_nt
-        per_dev = (N + visible - 1) // visible
-        fits = all(torch.cuda.mem_get_info(i)[0] > per_dev * 2.3 * s_len + (4 << 30) for i in range(min(N, visible)))
-        if fits:
-            s_parts = [sharding.shard_range_c(s_len * N, N, k) for k in range(N)]
-            s_lens = [hi - lo for lo, hi in s_parts]
-            s_in = [torch.empty(x, dtype=torch.uint8, device=d) for x, d in zip(s_lens, devs)]
-            s_pk = [torch.empty(x // 32, dtype=torch.int64, device=d) for x, d in zip(s_lens, devs)]
-            for t, (lo, _) in zip(s_in, s_parts):
-                devutil.fill_random_acgt(t, args.seed + 4, first_nt=lo)
-            sync_all()
-            b_in, b_pk, b_len, b_words = arrays(s_in), arrays(s_pk), sizes(s_lens), sizes([x // 32 for x in s_lens])
-            run_encode(b_in, b_len, b_pk, b_words)
-            reps = 8
-            s_ms = [(ctypes.c_float * N)() for _ in range(reps)]
-            sync_all()
-            t1 = time.perf_counter()
-            for r in range(reps):
-                run_encode(b_in, b_len, b_pk, b_words, s_ms[r])
-            sync_all()
-            shard_wall = (time.perf_counter() - t1) / reps
-            for k in range(N):
-                shard_rows[k] = {"nt": s_lens[k], "first_nt": s_parts[k][0], "encode_ms": stats_ms([float(s_ms[r][k]) for r in range(reps)]),
-                                 "wall_ms_per_encode_all_ranks": round(shard_wall * 1e3, 4)}
-            if verified is not None:
-                backs = sharding.bits_to_n_sharded_dev(s_pk, s_lens)
-                for k in range(N):
-                    shard_rows[k]["round_trip_verified"] = devutil.count_mismatch(s_in[k], backs[k]) == 0
-                    verified = verified and shard_rows[k]["round_trip_verified"]
-                del backs
-            del s_in, s_pk
-        else:
-            shard_rows = [{"skipped": "needs %.0f GiB of free HBM per device" % ((per_dev * 2.3 * s_len + (4 << 30)) / 2**30)}] * N
-
-    rows = []
-    for k in range(N):
-        enc_list = [float(ms_e[i][k]) for i in range(args.steps)]
-        dec_list = [float(ms_d[i][k]) for i in range(args.steps)]
-        enc_ms, dec_ms = statistics.fmean(enc_list), statistics.fmean(dec_list)
-        ident = {"rank": k, "local_rank": k, "pid": os.getpid()}
-        ident.update(devutil.device_identity(k % visible))
-        props = torch.cuda.get_device_properties(k % visible)
-        ident.update({"name": props.name, "uuid": str(getattr(props, "uuid", "")) or None, "hbm_GiB": round(props.total_memory / 2**30, 1)})
-        ident.update({
-            "nt": lens_l[k], "first_nt": parts[k][0], "encode_ms": stats_ms(enc_list), "decode_ms": stats_ms(dec_list),
-            "encode_gnts": round(lens_l[k] / (enc_ms * 1e-3) / 1e9, 1), "decode_gnts": round(lens_l[k] / (dec_ms * 1e-3) / 1e9, 1),
-            "encode_frac": round(gbs(BYTES_PER_NT * lens_l[k], enc_ms) / HBM_PEAK_GBS, 4),
-            "decode_frac": round(gbs(BYTES_PER_NT * lens_l[k], dec_ms) / HBM_PEAK_GBS, 4),
-            "encode_read_view_frac": round(gbs(lens_l[k], enc_ms) / HBM_PEAK_GBS, 4),
-            "fused_ms_median": None, "configs4_shard": shard_rows[k]})
-        rows.append(ident)
-
-    nt_per_step = 2 * n_global
-    value = nt_per_step * args.steps / elapsed / 1e9
-    r0 = rows[0]
-    enc_ms0, dec_ms0 = r0["encode_ms"]["mean"], r0["decode_ms"]["mean"]
-    enc_slow, dec_slow = max(r["encode_ms"]["mean"] for r in rows), max(r["decode_ms"]["mean"] for r in rows)
-    span = lambda key: {"min": min(r[key] for r in rows), "max": max(r[key] for r in rows)}
-    roof = lambda name, ms, st: {
-        "kernel": name, "bound": "hbm", "achieved": round(gbs(BYTES_PER_NT * lens_l[0], ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(gbs(BYTES_PER_NT * lens_l[0], ms) / HBM_PEAK_GBS, 4), "traffic": None,
-        "traffic_source": "not measured at N > 1 (the N = 1 line measures it live with rocprofv3 --pmc)", "avg_kernel_ms": round(ms, 4), "kernel_ms": st,
-        "frac_at_median": round(gbs(BYTES_PER_NT * lens_l[0], st["median"]) / HBM_PEAK_GBS, 4),
-        "frac_at_min": round(gbs(BYTES_PER_NT * lens_l[0], st["min"]) / HBM_PEAK_GBS, 4),
-        "algorithmic_bytes_per_launch": int(BYTES_PER_NT * lens_l[0]), "of": "device 0's shard (HIP events on its stream); all devices in roofline_over_ranks"}
-    line = {
-        "metric": "Gnt/s encode+decode on 16 GiB random ACGT; % HBM read roofline at 1/8 GPU",
-        "value": round(value, 3), "unit": "Gnt/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {
-            "workload": "n_to_bits encode + bits_to_n decode of a device-resident uniform random ACGT buffer, "
-                        "%.3g GiB (2^%d nt) per GPU" % (n_per / 2**30, args.log2_nt),
-            "nt_per_gpu": n_per, "nt_per_step": nt_per_step, "seed": hex(args.seed),
-            "sharding": "contiguous chunks on word boundaries (cnt_shard_range), shard k resident on device k, no data-path collective",
-            "launch": "single process: cnt_n_to_bits_sharded_dev / cnt_bits_to_n_sharded_dev enqueue every shard on its device's own stream "
-                      "and wait for all (one synchronous call per direction and step)",
-            "encode_kernel": dict(devutil.variants("encode"))[devutil.get_tuning("encode")],
-            "decode_kernel": dict(devutil.variants("decode"))[devutil.get_tuning("decode")],
-        },
-        "encode_gnts_per_gpu": round(lens_l[0] / (enc_ms0 * 1e-3) / 1e9, 3), "decode_gnts_per_gpu": round(lens_l[0] / (dec_ms0 * 1e-3) / 1e9, 3),
-        "encode_gnts_all_gpus": round(n_global / (enc_slow * 1e-3) / 1e9, 3), "decode_gnts_all_gpus": round(n_global / (dec_slow * 1e-3) / 1e9, 3),
-        "hbm_read_roofline_frac_encode_per_gpu": round(n_per / (enc_slow * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": dict(roof("n_to_bits (encode)", enc_ms0, r0["encode_ms"]),
-                         read_only_view={"achieved": round(gbs(lens_l[0], enc_ms0), 1), "frac": round(gbs(lens_l[0], enc_ms0) / HBM_PEAK_GBS, 4)}),
-        "roofline_decode": roof("bits_to_n (decode)", dec_ms0, r0["decode_ms"]),
-        "roofline_over_ranks": {"encode_frac": span("encode_frac"), "decode_frac": span("decode_frac"), "encode_read_view_frac": span("encode_read_view_frac")},
-        "ranks": rows,
-        "devices": {"distinct": len({r.get("uuid") or r["pci_bus_id"] for r in rows}), "visible": visible, "shared_gpu_test_hook": shared_gpu and visible < N,
-                    "data_path_collective": None, "control_plane": None, "processes": 1},
-        "verified": verified,
-        "value_definition": "nucleotides converted per second over all devices: each step encodes nt_per_gpu and decodes nt_per_gpu on every "
-                            "device (nt_per_step = 2 x n_gpus x nt_per_gpu); wall clock around the K steps, device-synchronised on both sides",
-    }
-    sh = [r["configs4_shard"] for r in rows if r.get("configs4_shard") and "encode_ms" in r["configs4_shard"]]
-    if sh:
-        tot = sum(x["nt"] for x in sh)
-        slow = max(x["encode_ms"]["median"] for x in sh)
-        line["configs4_sharded_encode"] = {
-            "what": "BASELINE.json configs[4]: n_to_bits encode of this run's share of '256 GiB over 8 GPUs' -- a 2^%d-nt (%.0f GiB) contiguous "
-                    "chunk per GPU (cnt_shard_range), all devices at once from one process, no collective; at N = 8 the whole 256 GiB"
-                    % (args.shard_log2_nt, 2**args.shard_log2_nt / 2**30),
-            "nt_per_gpu": sh[0]["nt"], "total_GiB": round(tot / 2**30, 1), "ranks_measured": len(sh),
-            "per_gpu_gnts": {"min": round(min(x["nt"] / (x["encode_ms"]["median"] * 1e-3) / 1e9 for x in sh), 1),
-                             "max": round(max(x["nt"] / (x["encode_ms"]["median"] * 1e-3) / 1e9 for x in sh), 1)},
-            "aggregate_gnts": round(tot / shard_wall / 1e9, 1),
-            "aggregate_definition": "all devices' nucleotides / wall time per cnt_n_to_bits_sharded_dev call (8 back-to-back calls); per-GPU "
-                                    "figures from each device's own HIP events",
-            "aggregate_gnts_from_slowest_rank_events": round(tot / (slow * 1e-3) / 1e9, 1),
-            "per_gpu_frac": {"min": round(min(gbs(BYTES_PER_NT * x["nt"], x["encode_ms"]["median"]) for x in sh) / HBM_PEAK_GBS, 4),
-                             "max": round(max(gbs(BYTES_PER_NT * x["nt"], x["encode_ms"]["median"]) for x in sh) / HBM_PEAK_GBS, 4)},
-            "per_gpu_read_view_frac": {"min": round(min(gbs(x["nt"], x["encode_ms"]["median"]) for x in sh) / HBM_PEAK_GBS, 4),
-                                       "max": round(max(gbs(x["nt"], x["encode_ms"]["median"]) for x in sh) / HBM_PEAK_GBS, 4)},
-        }
-    print(json.dumps(line), flush=True)
-
-
 def main():
     args = parse_args()
     import numpy as np
@@ -811,7 +227,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
-            return main_single_process(args)  # no launcher: one process drives the N devices (cnt_*_sharded_dev)
+            from bench_single_process import main_single_process
+
+            return main_single_process(args)  # no launcher: one process drives the N devices (cnt_*_sharded_dev_enqueue)
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -1251,14 +669,25 @@ def main():
                 line["host_tier"] = {
                     "pcie_ceiling": dict(pcie, what="pinned hipMemcpy of 1 GiB, median of 5, same run"),
                     "frac_of_pcie_ceiling_at_2^%d" % HOST_TIER_LOG2[-1]: frac,
+                    "timing_conventions": {
+                        "what": "the same host-slice call under the three ways a caller can time it, microseconds per call: `drop_inside` = result "
+                                "allocated AND the previous one freed inside the timed loop (the reference's harness, benches/bench_n_to_bits.rs:6-7; on "
+                                "this host munmap alone is ~47 ms per GiB of huge pages, 120 ms per GiB of 4-KiB pages, with or without HIP in the "
+                                "process: bench/munmap_lab.cpp), `drop_outside` = allocated inside, freed later, `into` = the `_into` form of the "
+                                "mirrors (n_to_bits_hip_into / bits_to_n_hip_into: the caller keeps the vector; rust/src/hip.rs, cute_nucleotides.hpp, "
+                                "n_to_bits.py)",
+                        **{"2^%d" % k: {fn: {"drop_inside_us": rows["2^%d" % k][fn + " fresh out us"],
+                                             "drop_outside_us": rows["2^%d" % k].get(fn + " fresh out, dropped later us"),
+                                             "into_us": rows["2^%d" % k][fn + "_into us"]}
+                                        for fn in ("n_to_bits_hip", "bits_to_n_hip")} for k in HOST_TIER_LOG2 if k >= 26}},
                     "fresh_over_reused_at_2^%d" % HOST_TIER_LOG2[-1]: {
-                        "what": "time of a call whose output is allocated inside it over the time into a reused output; `drop_inside` also frees the "
-                                "PREVIOUS result inside the timed loop (what criterion's iter does; on this host munmap costs ~47 ms per GiB of huge pages, "
-                                "120 ms per GiB of 4-KiB pages, with or without HIP in the process: bench/munmap_lab.cpp), `drop_outside` frees it later",
+                        "what": "time of a call whose output is allocated inside it over the time into a reused output (see timing_conventions)",
                         "n_to_bits_hip": {"drop_inside": round(big["n_to_bits_hip fresh out us"] / big["n_to_bits_hip reused out us"], 3),
-                                          "drop_outside": round(big["n_to_bits_hip fresh out, dropped later us"] / big["n_to_bits_hip reused out us"], 3)},
+                                          "drop_outside": round(big["n_to_bits_hip fresh out, dropped later us"] / big["n_to_bits_hip reused out us"], 3),
+                                          "into": round(big["n_to_bits_hip_into us"] / big["n_to_bits_hip reused out us"], 3)},
                         "bits_to_n_hip": {"drop_inside": round(big["bits_to_n_hip fresh out us"] / big["bits_to_n_hip reused out us"], 3),
-                                          "drop_outside": round(big["bits_to_n_hip fresh out, dropped later us"] / big["bits_to_n_hip reused out us"], 3)}},
+                                          "drop_outside": round(big["bits_to_n_hip fresh out, dropped later us"] / big["bits_to_n_hip reused out us"], 3),
+                                          "into": round(big["bits_to_n_hip_into us"] / big["bits_to_n_hip reused out us"], 3)}},
                     "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread; "
                             "`fresh out` allocates the output inside the timed call like the reference's functions do; microseconds per call "
                             "at 2^k nt (GiB/s of the fresh-out calls are in the crossover table)",

@@ -1,0 +1,412 @@
+"""Measurement helpers of bench.py (the repo-root driver contract): statistics, HIP-event timing loops, the same-run
+ceilings, the 5-letter / packed-ops / host-tier / PCIe blocks of the N = 1 line and the live HBM-traffic measurement.
+bench.py keeps argument parsing, the timed region, the CPU-baseline leg (the only code that may touch oracle/) and the
+JSON line; `python bench.py --gpus N` without a launcher is bench/bench_single_process.py.  Imported by bench.py as a
+plain module from this directory (the name `bench` belongs to bench.py itself)."""
+import ctypes
+import glob
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HOST_TIER_LOG2 = (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)  # sizes of the host-tier / one-CPU-thread crossover table
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_NT = 1.25    # algorithmic bytes per nucleotide, each direction
+
+
+def physical_cores(cpus):
+    """distinct (package, core) pairs among the CPUs this process may run on"""
+    seen = set()
+    for c in cpus:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            return None
+    return len(seen)
+
+
+def sockets():
+    try:
+        return len({open(os.path.join(d, "topology", "physical_package_id")).read().strip()
+                    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*") if os.path.exists(os.path.join(d, "topology"))})
+    except OSError:
+        return None
+
+
+def stats_ms(ms):
+    """mean / median / min / max and, from 10 samples on, p10 / p90 (decode's launches spread 3-9 % on one box with the
+    clock flat: profiles/r04_decode_spread.md -- a mean alone hides that)"""
+    s = sorted(ms)
+    out = {"mean": round(statistics.fmean(ms), 4), "median": round(statistics.median(ms), 4), "min": round(s[0], 4),
+           "max": round(s[-1], 4), "n": len(ms)}
+    if len(s) >= 10:
+        out["p10"], out["p90"] = round(s[len(s) // 10], 4), round(s[(9 * len(s)) // 10], 4)
+    return out
+
+
+def gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9
+
+
+def timed_calls(torch, fn, iters, warm=1):
+    """[ms] of `iters` individual fn() calls, each between two HIP events on torch's current stream (the stream
+    the C ABI is handed)."""
+    for _ in range(warm):
+        fn()
+    out = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return out
+
+
+def timed_queued(torch, fn, reps, queue, warm=1):
+    """[ms per call] of `reps` measurements, each `queue` back-to-back fn() calls between ONE pair of HIP events: the
+    average launch duration with the launches queued behind each other, as in the timed region of the headline (and
+    as rocprofv3's kernel trace sees them).  A single call between two events also counts the 10-50 us the host needs
+    to get from the event record to the launch -- 5 % of a 0.2 ms kernel at the 1 GiB configs."""
+    for _ in range(warm):
+        fn()
+    out = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(queue):
+            fn()
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1) / queue)
+    return out
+
+
+def numpy_pack(n):
+    """(byte>>1)&3, 32 codes per u64, LSB first (n_to_bits.rs:38-43, :85) -- three lines of numpy for the sampled
+    check of the TIMED packed buffer; bench.py touches oracle/ only in cpu_baseline()"""
+    import numpy as np
+
+    c = ((n >> 1) & 3).astype(np.uint64).reshape(-1, 32)
+    return (c << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+
+
+def load_probes():
+    """bench/libcnt_probes.so (built by __graft_entry__.build(), travels with the snapshot): no-arithmetic streams
+    issued like the shipped kernels, for the same-run ceilings.  None if it is not there."""
+    path = os.path.join(ROOT, "bench", "libcnt_probes.so")
+    if not os.path.exists(path):
+        return None
+    P = ctypes.CDLL(path)
+    P.probe_shipped.restype = ctypes.c_int
+    P.probe_shipped.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    return P
+
+
+def measure_ceilings(torch, P, d_a, d_b, nbytes, iters=5):
+    """TB/s (decimal) of the five no-arithmetic streams over the headline's own buffers: d_a is only read, d_b is
+    overwritten (call after verification).  nbytes = the 16-B-per-lane side (the ASCII side of the codec)."""
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = {}
+    for name, kind, moved in (("read_only", 0, nbytes), ("write_only", 4, nbytes), ("copy_1to1", 1, 2 * nbytes),
+                              ("read4_write1_encode_shape", 2, 1.25 * nbytes), ("read1_write4_decode_shape", 3, 1.25 * nbytes)):
+        def call():
+            rc = P.probe_shipped(kind, d_a.data_ptr(), d_b.data_ptr(), nbytes, stream)
+            if rc:
+                raise RuntimeError("probe_shipped(%d) -> %d" % (kind, rc))
+        ms = timed_calls(torch, call, iters)
+        rows[name] = {"GBs": round(gbs(moved, statistics.median(ms)), 1), "best_GBs": round(gbs(moved, min(ms)), 1),
+                      "bytes_moved": int(moved), "ms_median": round(statistics.median(ms), 4)}
+    return rows
+
+
+def measure_codec5(torch, seed, log2_nt, reps=4, queue=4):
+    """SURVEY 8 f-1 on the driver line: the 5-letter codec (n_to_bits2 / bits_to_n2, n_to_bits2.rs:37-107) at the metric's
+    size on device-resident random ACGTN.  Algorithmic bytes per nucleotide 1 + 8/27 in each direction (27 nt per u64).
+    Verified in-run: the reference's own vector ("ATCGN" x 7, n_to_bits2.rs:276-277) through the same device entry
+    points, and decode(encode(x)) == x over the whole timed buffer."""
+    import numpy as np
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import devutil
+
+    n = 1 << log2_nt
+    words = (n + 26) // 27
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    packed = torch.empty(words, dtype=torch.int64, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    devutil.fill_random_acgtn(d, seed + 5)
+    enc = lambda: cn.n_to_bits2_dev(d, out=packed)
+    dec = lambda: cn.bits_to_n2_dev(packed, n, out=back)
+    e, dd = timed_queued(torch, enc, reps, queue, warm=1), timed_queued(torch, dec, reps, queue, warm=1)
+    ok = devutil.count_mismatch(d, back) == 0
+    kat = torch.from_numpy(np.frombuffer(b"ATCGN" * 7, dtype=np.uint8).copy()).to(dev)
+    kb = cn.n_to_bits2_dev(kat)
+    ok = ok and [int(x) & 0xFFFFFFFFFFFFFFFF for x in kb.cpu().tolist()] == [0x36A45D1F46D48BA3, 0x5D1F4]
+    ok = ok and bool(torch.equal(cn.bits_to_n2_dev(kb, 35), kat))
+    bpn = 1.0 + 8.0 / 27.0
+    row = lambda ms: {"ms": stats_ms(ms), "gnts": round(n / (statistics.median(ms) * 1e-3) / 1e9, 1),
+                      "achieved_GBs": round(gbs(bpn * n, statistics.median(ms)), 1), "frac": round(gbs(bpn * n, statistics.median(ms)) / HBM_PEAK_GBS, 4)}
+    out = {"what": "5-letter codec {A,C,G,T/U,N} (n_to_bits2.rs): 3 nt -> a + 5b + 25c, 27 nt per u64; device tier, 2^%d nt of random ACGTN "
+                   "(P(N) = 1/16), %d launches queued per HIP-event pair" % (log2_nt, queue),
+           "nt": n, "algorithmic_bytes_per_nt": round(bpn, 4), "encode": row(e), "decode": row(dd), "verified": bool(ok),
+           "encode_kernel": dict(devutil.variants("encode2"))[devutil.get_tuning("encode2")],
+           "decode_kernel": dict(devutil.variants("decode2"))[devutil.get_tuning("decode2")]}
+    del d, packed, back
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_packed_ops(torch, seed, log2_nt, reps=4, queue=5):
+    """SURVEY 8 f-4 on the driver line: the packed-domain operations at the metric's size (README.md:20-25,45 names them,
+    the reference does not implement them: parity unpinned by construction).  Algorithmic bytes per nucleotide: hamming
+    2 x 0.25 read, complement / reverse complement 0.25 read + 0.25 written, validate 1 read.  Verified in-run by
+    algebraic properties over the whole buffers: two independent uniform sequences differ in 3/4 of the positions,
+    hamming(x, complement(x)) == len, both complements are involutions, a generated ACGT buffer validates clean."""
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import devutil, packed_ops as po
+
+    n = 1 << log2_nt
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    devutil.fill_random_acgt(d, seed + 6)
+    x = cn.n_to_bits_dev(d)
+    devutil.fill_random_acgt(d, seed + 7)
+    y = cn.n_to_bits_dev(d)
+    out = torch.empty_like(x)
+    acc = torch.zeros(1, dtype=torch.int64, device=dev)  # the reductions ADD to a caller-owned counter: nothing but their kernel is timed
+    ops = (("hamming", 0.5, lambda: po.hamming_dev(x, y, n, acc=acc)),
+           ("complement", 0.5, lambda: po.complement_dev(x, n, out=out)),
+           ("reverse_complement", 0.5, lambda: po.reverse_complement_dev(x, n, out=out)),
+           ("validate", 1.0, lambda: po.validate_dev(d, acc=acc)))
+    rows = {}
+    for name, bpn, fn in ops:
+        ms = timed_queued(torch, fn, reps, queue, warm=1)
+        med = statistics.median(ms)
+        rows[name] = {"ms": stats_ms(ms), "bytes_per_nt": bpn, "gnts": round(n / (med * 1e-3) / 1e9, 1),
+                      "achieved_GBs": round(gbs(bpn * n, med), 1), "frac": round(gbs(bpn * n, med) / HBM_PEAK_GBS, 4)}
+    dist = int(po.hamming_dev(x, y, n).item())
+    ok = abs(dist / n - 0.75) < 1e-3
+    comp = po.complement_dev(x, n)
+    ok = ok and int(po.hamming_dev(x, comp, n).item()) == n
+    ok = ok and bool(torch.equal(po.complement_dev(comp, n), x))
+    del comp
+    rc = po.reverse_complement_dev(x, n)
+    ok = ok and bool(torch.equal(po.reverse_complement_dev(rc, n), x))
+    del rc
+    ok = ok and int(po.validate_dev(d).item()) == 0
+    rows.update({"what": "packed-domain operations on 2-bit words without decoding; device tier, 2^%d nt, %d calls queued per HIP-event pair"
+                         % (log2_nt, queue), "nt": n, "verified": bool(ok), "parity": "unpinned (no reference vectors exist); property checks in-run"})
+    del d, x, y, out
+    torch.cuda.empty_cache()
+    return rows
+
+
+def measure_pcie(torch, nbytes=1 << 30, reps=5):
+    """Same-run PCIe ceilings for the host tier: hipMemcpy between PINNED host memory and the device, both directions,
+    GiB/s -- what a transfer-bound host-pointer call could reach with free staging."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    h = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    h.zero_()
+    out = {}
+    for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
+        ms = timed_calls(torch, fn, reps, warm=1)
+        out[name + "_GiBs"] = round(nbytes / (statistics.median(ms) * 1e-3) / 2**30, 2)
+    del h, d
+    return out
+
+
+def measure_host_tier(seed):
+    """The drop-in host-pointer tier (cnt_n_to_bits / cnt_bits_to_n: H2D + kernel + D2H inside, PCIe-bound) at the
+    sizes of the crossover table, timed like the reference's harness times its functions: one calling thread, the
+    output allocated inside every timed call (np.empty -> fresh pages, like a fresh Vec), and again into a reused
+    output.  GiB/s of nucleotides.  Never part of `value`."""
+    import numpy as np
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(seed)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 1 << HOST_TIER_LOG2[-1], dtype=np.uint8)]
+    rows = {}
+    for log2 in HOST_TIER_LOG2:
+        m = 1 << log2
+        n = big[:m]
+        words = m // 32
+        bits = np.empty(words, dtype=np.uint64)
+        back = np.empty(m, dtype=np.uint8)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+
+        def enc_fresh():
+            out = np.empty(words, dtype=np.uint64)
+            return L.cnt_n_to_bits(p(n), m, p(out), words)
+
+        def dec_fresh():
+            out = np.empty(m, dtype=np.uint8)
+            return L.cnt_bits_to_n(p(bits), words, m, p(out))
+
+        kept = []  # "dropped later": the result outlives the call and is freed outside the timed loop (criterion's iter_with_large_drop)
+
+        def enc_fresh_kept():
+            out = np.empty(words, dtype=np.uint64)
+            kept.append(out)
+            return L.cnt_n_to_bits(p(n), m, p(out), words)
+
+        def dec_fresh_kept():
+            out = np.empty(m, dtype=np.uint8)
+            kept.append(out)
+            return L.cnt_bits_to_n(p(bits), words, m, p(out))
+
+        def enc_reuse():
+            return L.cnt_n_to_bits(p(n), m, p(bits), words)
+
+        def dec_reuse():
+            return L.cnt_bits_to_n(p(bits), words, m, p(back))
+
+        into_w, into_n = np.empty(words, dtype=np.uint64), np.empty(m, dtype=np.uint8)  # the caller's own vectors, kept across calls
+
+        def enc_into():  # the `_into` form of the mirrors (n_to_bits_hip_into): nothing allocated or dropped in the call
+            cn.n_to_bits_hip_into(n, into_w)
+            return 0
+
+        def dec_into():
+            cn.bits_to_n_hip_into(bits, m, into_n)
+            return 0
+
+        row = {}
+        for name, fn in (("n_to_bits_hip reused out", enc_reuse), ("bits_to_n_hip reused out", dec_reuse),
+                         ("n_to_bits_hip_into", enc_into), ("bits_to_n_hip_into", dec_into),
+                         ("n_to_bits_hip fresh out", enc_fresh), ("bits_to_n_hip fresh out", dec_fresh)):
+            assert fn() == 0
+            t0, k = time.perf_counter(), 0
+            while True:
+                fn()
+                k += 1
+                dt = time.perf_counter() - t0
+                if dt > 0.12 or k >= 20000:
+                    break
+            row[name] = round(m / (dt / k) / 2**30, 3)
+            row[name + " us"] = round(dt / k * 1e6, 2)
+        if log2 >= 26:  # large outputs: the same fresh-output calls with the DROP of the result outside the timed loop
+            for name, fn in (("n_to_bits_hip fresh out, dropped later", enc_fresh_kept), ("bits_to_n_hip fresh out, dropped later", dec_fresh_kept)):
+                reps = 3 if log2 >= 30 else 6
+                fn()
+                kept.clear()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                dt = time.perf_counter() - t0
+                kept.clear()
+                row[name + " us"] = round(dt / reps * 1e6, 2)
+        assert np.array_equal(back, n) and np.array_equal(into_n, n) and np.array_equal(into_w, bits)
+        rows["2^%d" % log2] = row
+    rows["placement"] = {"input": host_placement(big), "reused_output": host_placement(back)}
+    return rows
+
+
+def host_placement(arr):
+    """Where a host array's pages lie (NUMA nodes, share in transparent huge pages) and which CPU the caller is on: the host
+    tier's 1-GiB rows move by 15 % with these (profiles/r03_host_numa_placement.jsonl), so the line says what it ran on."""
+    out = {}
+    try:
+        addr = arr.ctypes.data + arr.nbytes // 2  # the middle: an madvise'd array is several mappings (numpy advises its interior)
+        start = None
+        for line in open("/proc/self/maps"):
+            lo, hi = (int(x, 16) for x in line.split()[0].split("-"))
+            if lo <= addr < hi:
+                start = lo
+                break
+        if start is not None:
+            for line in open("/proc/self/numa_maps"):
+                f = line.split()
+                if int(f[0], 16) == start:
+                    out["pages_per_node"] = {x.split("=")[0]: int(x.split("=")[1]) for x in f[2:] if x[0] == "N" and x[1:2].isdigit()}
+                    break
+            want, size, huge = "%x-" % start, None, None
+            hit = False
+            for line in open("/proc/self/smaps"):
+                if line.startswith(want):
+                    hit = True
+                elif hit and line.startswith("Size:"):
+                    size = int(line.split()[1])
+                elif hit and line.startswith("AnonHugePages:"):
+                    huge = int(line.split()[1])
+                    break
+            if size:
+                out["huge_page_share"] = round(huge / size, 3)
+        cpu = ctypes.CDLL(None).sched_getcpu()
+        node = [d for d in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu) if d.startswith("node")]
+        out["caller_cpu"] = cpu
+        out["caller_node"] = node[0] if node else None
+    except (OSError, ValueError, AttributeError, IndexError):
+        pass
+    return out
+
+
+def gpu_numa_node(bdf):
+    try:
+        return int(open("/sys/bus/pci/devices/%s/numa_node" % str(bdf).lower()).read())
+    except (OSError, ValueError):
+        return None
+
+
+def crossover(host_rows, cpu_rows):
+    """smallest table size from which the host tier stays ahead of ONE CPU thread running the reference's fastest
+    AVX2 path, both allocating their output inside the call (the reference's bench rule)"""
+    out = {}
+    for gpu_key, cpu_key in (("n_to_bits_hip fresh out", "n_to_bits_movemask"), ("bits_to_n_hip fresh out", "bits_to_n_shuffle")):
+        sizes = [k for k in host_rows if k in cpu_rows and cpu_key in cpu_rows[k]]
+        ahead = [host_rows[k][gpu_key] > cpu_rows[k][cpu_key] for k in sizes]
+        first = next((sizes[i] for i in range(len(sizes)) if all(ahead[i:])), None)
+        out[gpu_key.split()[0] + " vs " + cpu_key] = {
+            "host_tier_ahead_from": first,
+            "table_GiBs": {k: [host_rows[k][gpu_key], cpu_rows[k][cpu_key]] for k in sizes},
+            "columns": ["host tier (PCIe inside)", "one CPU thread, " + cpu_key]}
+    return out
+
+
+def measure_traffic_live(log2_nt, timeout_s=90):
+    """HBM bytes per launch of the two timed kernels, measured by THIS run on THIS box: two child processes of
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has 4 counter slots,
+    3 + 2 do not fit; counters are never combined with any other tracing domain) over bench/pmc_workload.py
+    --codec-only, i.e. a read-only and a write-only probe of known size for the calibration (gfx950 reports half of
+    wide coalesced reads, MI355X_MICROARCH.md section HBM) followed by the encode and decode kernels at the same
+    size as the headline.  Returns the summary of bench/parse_profiles.py:traffic_summary, or {"error": ...}."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    sys.path.insert(0, os.path.join(ROOT, "bench"))
+    import parse_profiles
+
+    tmp = tempfile.mkdtemp(prefix="cnt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        csvs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench", "pmc_workload.py"), "--log2-nt", str(log2_nt), "--reps", "2", "--codec-only"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            csvs[counter] = os.path.join(out, "pmc_counter_collection.csv")
+            if r.returncode != 0 or not os.path.exists(csvs[counter]):
+                return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout[-300:])}
+        return parse_profiles.traffic_summary(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], 1 << log2_nt, "live")
+    except Exception as exc:  # noqa: BLE001 -- the headline must not die with its evidence leg
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -76,6 +76,15 @@ int main(int argc, char** argv) {
         });
         const auto bits = n_to_bits::n_to_bits_hip(n);  // get_bits(10000), :76-78
         bench_function("bits_to_n", "bits_to_n_hip", 40000, [&] { g_sink += n_to_bits::bits_to_n_hip(bits, 40000).back(); });
+        // the `_into` idiom: the caller's vector is reused, nothing is allocated or dropped inside the timed call
+        Vec<uint64_t> w_into;
+        Vec<uint8_t> n_into;
+        bench_function("n_to_bits", "n_to_bits_hip_into", 40000, [&] { n_to_bits::n_to_bits_hip_into(n.data(), n.size(), w_into); g_sink += w_into.back(); });
+        bench_function("bits_to_n", "bits_to_n_hip_into", 40000, [&] { n_to_bits::bits_to_n_hip_into(bits.data(), bits.size(), 40000, n_into); g_sink += n_into.back(); });
+        if (!(w_into == bits) || !(n_into == n)) {
+            fprintf(stderr, "_into mismatch at 40000 nt\n");
+            return 2;
+        }
         // the same 40 000 nucleotides resident in HBM: one enqueue + one stream sync per call
         void *d_n = nullptr, *d_bits = nullptr, *d_back = nullptr;
         if (cnt_dev_alloc(&d_n, 40000) || cnt_dev_alloc(&d_bits, 1250 * 8) || cnt_dev_alloc(&d_back, 40000) ||
@@ -120,6 +129,19 @@ int main(int argc, char** argv) {
         const auto bits = n_to_bits::n_to_bits_hip(n);
         snprintf(nm, sizeof nm, "bits_to_n_hip/2^%zu", log2);
         bench_function("host-tier", nm, len, [&] { g_sink += n_to_bits::bits_to_n_hip(bits, len).back(); });
+        // three timing conventions for the same call: result dropped INSIDE the timed call (the two rows above: what the
+        // reference's harness does, bench_n_to_bits.rs:6-7), `_into` a vector the caller keeps (below), and the C ABI into
+        // reused / fresh-malloc outputs further down
+        Vec<uint64_t> w_into;
+        Vec<uint8_t> n_into;
+        snprintf(nm, sizeof nm, "n_to_bits_hip_into/2^%zu", log2);
+        bench_function("host-tier", nm, len, [&] { n_to_bits::n_to_bits_hip_into(n.data(), len, w_into); g_sink += w_into.back(); });
+        snprintf(nm, sizeof nm, "bits_to_n_hip_into/2^%zu", log2);
+        bench_function("host-tier", nm, len, [&] { n_to_bits::bits_to_n_hip_into(bits.data(), bits.size(), len, n_into); g_sink += n_into.back(); });
+        if (!(w_into == bits) || !(n_into == n)) {
+            fprintf(stderr, "_into mismatch at 2^%zu\n", log2);
+            return 2;
+        }
         // the same calls through the C ABI into caller-owned, already-touched outputs: what the
         // library itself costs once the fresh-Vec page faults of the rows above are taken away
         std::vector<uint64_t> bits_out(bits.size());

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libcute_nt_hip.so")
 CNT_OK, CNT_EINVAL, CNT_ECAP, CNT_ELEN, CNT_ENODEV, CNT_ERANGE = 0, 1, 2, 3, 4, 5
 CNT_STRICT_LUT = 0x1
 CNT_TAIL_LUT = 0x4
+CNT_QUEUE_TIMED = 0x1
 
 _vp, _sz, _u64, _int, _uint = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint
 
@@ -45,6 +46,15 @@ SIGNATURES = {
     "cnt_bits_to_n_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
     "cnt_n_to_bits2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
     "cnt_bits_to_n2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
+    "cnt_sharded_dev_open": (_int, [_int, _uint, ctypes.POINTER(_vp)]),
+    "cnt_sharded_dev_close": (_int, [_vp]),
+    "cnt_sharded_dev_shards": (_int, [_vp, ctypes.POINTER(_int)]),
+    "cnt_n_to_bits_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
+    "cnt_bits_to_n_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
+    "cnt_n_to_bits2_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
+    "cnt_bits_to_n2_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
+    "cnt_sharded_dev_wait": (_int, [_vp, _vp]),
+    "cnt_sharded_dev_op_ms": (_int, [_vp, _sz, _vp]),
     "cnt_n_to_bits_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
     "cnt_bits_to_n_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
     "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),

@@ -153,6 +153,7 @@ int cnt_device_numa_node(int device, int* node) {
 }
 
 static int release_thread_ctx() {
+    t_queues.release();
     t_ctx.pool.stop();
     for (auto& kv : t_ctx.per_device) kv.second.release();
     t_ctx.per_device.clear();
@@ -250,6 +251,50 @@ int cnt_n_to_bits2_sharded_dev(const void* const* d_n, const size_t* n_len, void
 int cnt_bits_to_n2_sharded_dev(const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, int ndev,
                                unsigned flags, float* shard_ms) {
     return sharded_dev_decode(d_bits, words, len, d_out, ndev, flags, shard_ms, decode2_dev);
+}
+
+// the same work, enqueue-only: a caller-owned queue (one stream per shard), any number of ops queued ahead, one wait
+int cnt_sharded_dev_open(int ndev, unsigned flags, void** queue) {
+    ShardQueue* q = nullptr;
+    if (!queue) return CNT_EINVAL;
+    const int rc = shard_queue_open(ndev, flags, &q);
+    *queue = q;
+    return rc;
+}
+int cnt_sharded_dev_close(void* queue) { return shard_queue_close(queue); }
+int cnt_sharded_dev_wait(void* queue, float* shard_ms) { return shard_queue_wait(queue, shard_ms); }
+int cnt_sharded_dev_shards(void* queue, int* ndev) {
+    ShardQueue* q = shard_queue_of(queue);
+    if (!q || !ndev) return CNT_EINVAL;
+    *ndev = q->ndev;
+    return CNT_OK;
+}
+int cnt_sharded_dev_op_ms(void* queue, size_t op, float* shard_ms) {
+    ShardQueue* q = shard_queue_of(queue);
+    if (!q || !shard_ms || !q->timed || op >= q->last_ops) return CNT_EINVAL;
+    for (int k = 0; k < q->ndev; ++k) shard_ms[k] = q->op_ms[k][op];
+    return CNT_OK;
+}
+static int queue_encode(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags,
+                        int (*fn)(const void*, size_t, void*, size_t, unsigned, hipStream_t)) {
+    if (!d_n || !n_len || !d_out || !out_words) return CNT_EINVAL;
+    return shard_queue_enqueue(queue, [&](int k, hipStream_t s) { return fn(d_n[k], n_len[k], d_out[k], out_words[k], flags, s); });
+}
+static int queue_decode(void* queue, const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, unsigned flags, dec_fn fn) {
+    if (!d_bits || !words || !len || !d_out) return CNT_EINVAL;
+    return shard_queue_enqueue(queue, [&](int k, hipStream_t s) { return fn(d_bits[k], words[k], len[k], d_out[k], flags, s); });
+}
+int cnt_n_to_bits_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags) {
+    return queue_encode(queue, d_n, n_len, d_out, out_words, flags, encode_dev);
+}
+int cnt_bits_to_n_sharded_dev_enqueue(void* queue, const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, unsigned flags) {
+    return queue_decode(queue, d_bits, words, len, d_out, flags, decode_dev);
+}
+int cnt_n_to_bits2_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags) {
+    return queue_encode(queue, d_n, n_len, d_out, out_words, flags, encode2_dev);
+}
+int cnt_bits_to_n2_sharded_dev_enqueue(void* queue, const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, unsigned flags) {
+    return queue_decode(queue, d_bits, words, len, d_out, flags, decode2_dev);
 }
 
 // ---- device tier --------------------------------------------------------------------

@@ -101,6 +101,20 @@ inline Vec<uint8_t> bits_to_n_hip(const std::vector<uint64_t, A>& bits, size_t l
     return bits_to_n_hip(bits.data(), bits.size(), len);
 }
 
+/// `_into` forms: the same codecs writing into a vector the CALLER owns (resized without zero-fill, capacity reused).  A
+/// loop that times like the reference's harness -- result allocated AND dropped inside the timed call,
+/// benches/bench_n_to_bits.rs:6-7 -- then pays neither the page faults of a fresh allocation nor the munmap of the
+/// dropped one (1-GiB decode: 22 ms instead of 74 ms, BENCH_r03 host_tier).  Same results and exceptions.
+inline void n_to_bits_hip_into(const uint8_t* n, size_t len, Vec<uint64_t>& out, bool strict_lut = false, bool tail_lut = false) {
+    out.resize(cnt_words_for(len));
+    detail::check(cnt_n_to_bits_ex(n, len, out.data(), out.size(), (strict_lut ? CNT_STRICT_LUT : 0u) | (tail_lut ? CNT_TAIL_LUT : 0u)));
+}
+inline void bits_to_n_hip_into(const uint64_t* bits, size_t words, size_t len, Vec<uint8_t>& out) {
+    if (len > (words << 5)) detail::check(CNT_ELEN);
+    out.resize(len);
+    detail::check(cnt_bits_to_n(bits, words, len, out.data()));
+}
+
 /// The same, cut into contiguous chunks over `ndev` GPUs (<= 0: all visible), no collective.
 inline Vec<uint64_t> n_to_bits_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
     Vec<uint64_t> out(cnt_words_for(len));
@@ -137,6 +151,16 @@ inline Vec<uint8_t> bits_to_n2_hip(const uint64_t* bits, size_t words, size_t le
 template <class A>
 inline Vec<uint8_t> bits_to_n2_hip(const std::vector<uint64_t, A>& bits, size_t len) {
     return bits_to_n2_hip(bits.data(), bits.size(), len);
+}
+
+inline void n_to_bits2_hip_into(const uint8_t* n, size_t len, Vec<uint64_t>& out) {
+    out.resize(cnt_words2_for(len));
+    detail::check(cnt_n_to_bits2(n, len, out.data(), out.size()));
+}
+inline void bits_to_n2_hip_into(const uint64_t* bits, size_t words, size_t len, Vec<uint8_t>& out) {
+    if (words > SIZE_MAX / 27 || len > words * 27) detail::check(CNT_ELEN);
+    out.resize(len);
+    detail::check(cnt_bits_to_n2(bits, words, len, out.data()));
 }
 
 /// The 5-letter codec over `ndev` GPUs (shards are whole 128-word tiles), no collective.
@@ -193,6 +217,64 @@ inline void bits_to_n_hip_dev(const DeviceBuffer& bits, size_t words, size_t len
     detail::check(cnt_bits_to_n_dev(bits.data(), words, len, out.data(), 0u, nullptr));
 }
 inline void sync() { detail::check(cnt_dev_sync(nullptr)); }
+inline void set_device(int device) { detail::check(cnt_set_device(device)); }  // what DeviceBuffer allocates on
+
+/// Enqueue-only multi-GPU device tier (cnt_sharded_dev_open / *_enqueue / cnt_sharded_dev_wait): shard k resident on
+/// device k, one library stream per shard; every enqueue_* call queues that codec call on every shard and returns at
+/// once, wait() drains all of them.  Queue the decode of step s behind its encode, step s+1 behind that, wait once: the
+/// devices run back to back with the host a whole queue ahead (word w depends on nucleotides [32w, 32w+32) only,
+/// n_to_bits.rs:38-43 -- nothing needs a barrier).
+class ShardedDevQueue {
+   public:
+    explicit ShardedDevQueue(int ndev, bool timed = false) {
+        detail::check(cnt_sharded_dev_open(ndev, timed ? CNT_QUEUE_TIMED : 0u, &handle_));
+        detail::check(cnt_sharded_dev_shards(handle_, &ndev_));
+    }
+    ~ShardedDevQueue() { (void)cnt_sharded_dev_close(handle_); }
+    ShardedDevQueue(const ShardedDevQueue&) = delete;
+    ShardedDevQueue& operator=(const ShardedDevQueue&) = delete;
+    int shards() const { return ndev_; }
+    void enqueue_n_to_bits(const std::vector<const DeviceBuffer*>& n, const std::vector<size_t>& n_len, const std::vector<DeviceBuffer*>& out, bool strict_lut = false) {
+        if ((int)n.size() != ndev_ || (int)n_len.size() != ndev_ || (int)out.size() != ndev_) throw std::invalid_argument("one entry per shard");
+        std::vector<const void*> in(n.size());
+        std::vector<void*> o(n.size());
+        std::vector<size_t> cap(n.size());
+        for (size_t k = 0; k < n.size(); ++k) {
+            if (n_len[k] > n[k]->size_bytes()) throw std::out_of_range("enqueue_n_to_bits: n_len");
+            in[k] = n[k]->data();
+            o[k] = out[k]->data();
+            cap[k] = out[k]->size_bytes() / 8;
+        }
+        detail::check(cnt_n_to_bits_sharded_dev_enqueue(handle_, in.data(), n_len.data(), o.data(), cap.data(), strict_lut ? CNT_STRICT_LUT : 0u));
+    }
+    void enqueue_bits_to_n(const std::vector<const DeviceBuffer*>& bits, const std::vector<size_t>& words, const std::vector<size_t>& len, const std::vector<DeviceBuffer*>& out) {
+        if ((int)bits.size() != ndev_ || (int)words.size() != ndev_ || (int)len.size() != ndev_ || (int)out.size() != ndev_) throw std::invalid_argument("one entry per shard");
+        std::vector<const void*> in(bits.size());
+        std::vector<void*> o(bits.size());
+        for (size_t k = 0; k < bits.size(); ++k) {
+            if (len[k] > (words[k] << 5)) detail::check(CNT_ELEN);
+            if (words[k] * 8 > bits[k]->size_bytes() || len[k] > out[k]->size_bytes()) throw std::out_of_range("enqueue_bits_to_n: sizes");
+            in[k] = bits[k]->data();
+            o[k] = out[k]->data();
+        }
+        detail::check(cnt_bits_to_n_sharded_dev_enqueue(handle_, in.data(), words.data(), len.data(), o.data(), 0u));
+    }
+    /// waits for everything queued; per-shard device milliseconds of the batch (zeros unless timed)
+    std::vector<float> wait() {
+        std::vector<float> ms((size_t)ndev_, 0.f);
+        detail::check(cnt_sharded_dev_wait(handle_, ms.data()));
+        return ms;
+    }
+    std::vector<float> op_ms(size_t op) const {
+        std::vector<float> ms((size_t)ndev_, 0.f);
+        detail::check(cnt_sharded_dev_op_ms(handle_, op, ms.data()));
+        return ms;
+    }
+
+   private:
+    void* handle_ = nullptr;
+    int ndev_ = 0;
+};
 
 }  // namespace device
 

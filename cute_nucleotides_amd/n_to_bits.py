@@ -76,6 +76,32 @@ def bits_to_n_hip(bits, length):
     return out
 
 
+def _own_out(out, dtype, need, what):
+    if not isinstance(out, np.ndarray) or out.dtype != dtype or not out.flags.c_contiguous or not out.flags.writeable or out.size < need:
+        raise ValueError("%s: out must be a writable contiguous %s array with >= %d elements" % (what, np.dtype(dtype).name, need))
+
+
+def n_to_bits_hip_into(n, out, strict_lut=False, tail_lut=False):
+    """n_to_bits_hip into an array the CALLER owns (uint64, >= ceil(len/32) elements): the `_into` form of the Rust / C++
+    mirrors.  A loop that times like the reference's harness (result allocated and dropped inside the timed call,
+    benches/bench_n_to_bits.rs:6-7) pays neither fresh-page faults nor munmap this way.  Returns the view out[:words]."""
+    n = _u8(n)
+    words = lib().cnt_words_for(n.size)
+    _own_out(out, np.uint64, words, "n_to_bits_hip_into")
+    check(lib().cnt_n_to_bits_ex(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut)))
+    return out[:words]
+
+
+def bits_to_n_hip_into(bits, length, out):
+    """bits_to_n_hip into a caller-owned uint8 array (>= length elements); returns the view out[:length]."""
+    bits = _u64(bits)
+    if length > bits.size * 32:
+        check(_lib.CNT_ELEN)
+    _own_out(out, np.uint8, length, "bits_to_n_hip_into")
+    check(lib().cnt_bits_to_n(_p(bits), bits.size, length, _p(out)))
+    return out[:length]
+
+
 def n_to_bits_hip_sharded(n, ndev=0, strict_lut=False, tail_lut=False):
     """n_to_bits_hip with the buffer cut into contiguous chunks over `ndev` GPUs (0 = all)."""
     n = _u8(n)

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, lib
-from .n_to_bits import _dev_guard, _enqueue, _out_bytes, _out_words, _p, _u8, _u64, encode_flags
+from .n_to_bits import _dev_guard, _enqueue, _out_bytes, _out_words, _own_out, _p, _u8, _u64, encode_flags
 
 
 def n_to_bits2_hip(n, strict_lut=False, tail_lut=False):
@@ -30,6 +30,25 @@ def bits_to_n2_hip(bits, length):
     out = np.empty(length, dtype=np.uint8)
     check(lib().cnt_bits_to_n2(_p(bits), bits.size, length, _p(out)))
     return out
+
+
+def n_to_bits2_hip_into(n, out, strict_lut=False, tail_lut=False):
+    """n_to_bits2_hip into a caller-owned uint64 array (>= ceil(len/27) elements); returns the view out[:words]."""
+    n = _u8(n)
+    words = lib().cnt_words2_for(n.size)
+    _own_out(out, np.uint64, words, "n_to_bits2_hip_into")
+    check(lib().cnt_n_to_bits2_ex(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut)))
+    return out[:words]
+
+
+def bits_to_n2_hip_into(bits, length, out):
+    """bits_to_n2_hip into a caller-owned uint8 array (>= length elements); returns the view out[:length]."""
+    bits = _u64(bits)
+    if length > bits.size * 27:
+        check(_lib.CNT_ELEN)
+    _own_out(out, np.uint8, length, "bits_to_n2_hip_into")
+    check(lib().cnt_bits_to_n2(_p(bits), bits.size, length, _p(out)))
+    return out[:length]
 
 
 def n_to_bits2_hip_sharded(n, ndev=0, strict_lut=False, tail_lut=False):

@@ -170,3 +170,132 @@ def bits_to_n_sharded_dev(shards, lengths, outs=None, five_letter=False, want_ms
              _size_array(list(lengths)), _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), len(shards), 0, ms))
     outs = [o[:n] for o, n in zip(outs, lengths)]
     return (outs, list(ms)) if want_ms else outs
+
+
+class DevQueue:
+    """Enqueue-only form of the device-resident sharded tier (cnt_sharded_dev_open / *_enqueue / cnt_sharded_dev_wait): one
+    library stream per shard, any number of ops queued ahead, one wait.
+
+        with sharding.DevQueue(ndev, timed=True) as q:
+            for _ in range(steps):
+                q.n_to_bits(d_in, d_packed)             # returns at once
+                q.bits_to_n(d_packed, lens, d_out)      # queued behind the encode on every shard's stream
+            ms = q.wait()                               # per-shard device milliseconds of the whole batch
+            enc0 = q.op_ms(0)                           # ... and of each op
+
+    The tensors handed to an enqueue call are kept alive until the next wait(); whatever produced them on torch's streams
+    must be complete before the call (the queue's streams are the library's own)."""
+
+    def __init__(self, ndev=0, timed=False):
+        import ctypes
+
+        from . import _lib
+        from ._lib import check, lib
+
+        self._L = lib()
+        self._h = ctypes.c_void_p()
+        check(self._L.cnt_sharded_dev_open(ndev, _lib.CNT_QUEUE_TIMED if timed else 0, ctypes.byref(self._h)))
+        n = ctypes.c_int(0)
+        check(self._L.cnt_sharded_dev_shards(self._h, ctypes.byref(n)))
+        self.ndev, self.timed, self._keep, self.ops = n.value, timed, [], 0
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            from ._lib import check
+
+            h, self._h = self._h, None
+            self._keep = []
+            check(self._L.cnt_sharded_dev_close(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _own(self, shards):
+        if self._h is None:
+            raise ValueError("queue is closed")
+        if len(shards) != self.ndev:
+            raise ValueError("this queue drives %d shards, got %d" % (self.ndev, len(shards)))
+
+    def n_to_bits(self, shards, outs, five_letter=False, strict_lut=False, tail_lut=False):
+        """queue one encode of every shard (uint8 CUDA tensor on device k) into outs[k] (int64, >= words); returns at once"""
+        import torch
+
+        from ._lib import check
+        from .n_to_bits import encode_flags
+
+        self._own(shards)
+        words_for = self._L.cnt_words2_for if five_letter else self._L.cnt_words_for
+        for t, o in zip(shards, outs):
+            if not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+                raise ValueError("shards must be contiguous uint8 CUDA tensors")
+            if o.dtype != torch.int64 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < words_for(t.numel()):
+                raise ValueError("outs[k] must be a contiguous int64 CUDA tensor on shard k's device with >= words elements")
+        _check_placement(shards, outs)
+        fn = self._L.cnt_n_to_bits2_sharded_dev_enqueue if five_letter else self._L.cnt_n_to_bits_sharded_dev_enqueue
+        self._keep.append((shards, outs))
+        check(fn(self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+                 _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), _size_array([o.numel() for o in outs]), encode_flags(strict_lut, tail_lut)))
+        self.ops += 1
+
+    def bits_to_n(self, shards, lengths, outs, five_letter=False):
+        """queue one decode of every shard (int64 words on device k, lengths[k] nucleotides) into outs[k] (uint8, >= length)"""
+        import torch
+
+        from . import _lib
+        from ._lib import check
+
+        self._own(shards)
+        unit = 27 if five_letter else 32
+        if len(lengths) != len(shards) or len(outs) != len(shards):
+            raise ValueError("shards, lengths and outs must have one entry per shard")
+        for t, n, o in zip(shards, lengths, outs):
+            if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+                raise ValueError("shards must be contiguous int64 CUDA tensors")
+            if n > t.numel() * unit:
+                check(_lib.CNT_ELEN)
+            if o.dtype != torch.uint8 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < n:
+                raise ValueError("outs[k] must be a contiguous uint8 CUDA tensor on shard k's device with >= length elements")
+        _check_placement(shards, outs, lengths)
+        fn = self._L.cnt_bits_to_n2_sharded_dev_enqueue if five_letter else self._L.cnt_bits_to_n_sharded_dev_enqueue
+        self._keep.append((shards, outs))
+        check(fn(self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+                 _size_array(list(lengths)), _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), 0))
+        self.ops += 1
+
+    def wait(self):
+        """drain every shard's stream; returns the per-shard device milliseconds of the batch (zeros unless timed)"""
+        import ctypes
+
+        from ._lib import check
+
+        if self._h is None:
+            raise ValueError("queue is closed")
+        ms = (ctypes.c_float * self.ndev)()
+        try:
+            check(self._L.cnt_sharded_dev_wait(self._h, ms))
+        finally:
+            self._keep, self.last_ops, self.ops = [], self.ops, 0
+        return list(ms)
+
+    def op_ms(self, op):
+        """per-shard device milliseconds of op `op` of the batch the last wait() drained (timed queues)"""
+        import ctypes
+
+        from ._lib import check
+
+        ms = (ctypes.c_float * self.ndev)()
+        check(self._L.cnt_sharded_dev_op_ms(self._h, op, ms))
+        return list(ms)

@@ -139,7 +139,7 @@ int cnt_shard_worker_info(int k, int *device, int *numa_node, int *n_cpus, int *
 /* ---- multi-GPU device tier: shards already resident, one per device ---------------- */
 /* Arrays of ndev entries; shard k is device memory ON DEVICE k (ndev <= 0: all visible
  * devices; under cnt_test_alias_devices: device k % count).  The calling thread enqueues every
- * shard on a library-owned stream of its device -- the devices then run concurrently -- and
+ * shard on a library-owned stream of its own (on that shard's device) -- the devices then run concurrently -- and
  * returns when all have finished: no host staging, no collective, no helper threads.  The streams
  * are the library's own (non-blocking), so whatever produced the shards must be COMPLETE before the
  * call (synchronise the producing streams first); the outputs are complete when it returns.  Per-shard
@@ -154,6 +154,34 @@ int cnt_n_to_bits2_sharded_dev(const void *const *d_n, const size_t *n_len, void
                                int ndev, unsigned flags, float *shard_ms);
 int cnt_bits_to_n2_sharded_dev(const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out,
                                int ndev, unsigned flags, float *shard_ms);
+
+/* The same work ENQUEUE-ONLY, so that one thread keeps N devices busy back to back: a queue owns one library stream per
+ * shard (shard k on device k) and nothing else.  Each *_enqueue call queues ONE op -- that codec call on every shard --
+ * behind whatever the queue already holds and returns without waiting; cnt_sharded_dev_wait drains all shards.  Ops of
+ * one queue run in order per shard, shards never wait for each other (word w depends on nucleotides [32w, 32w+32) only,
+ * n_to_bits.rs:38-43), so a caller may queue the decode of step k behind its encode, and step k+1 behind that, and wait
+ * once: the host's per-launch cost (10-20 us per shard) stays off the devices' critical path.  The synchronous entry
+ * points above are exactly open-once + enqueue + wait on a queue cached per calling thread.
+ *   cnt_sharded_dev_open    ndev <= 0: all visible devices.  flags: CNT_QUEUE_TIMED records an event behind every op.
+ *   *_enqueue               arrays of ndev entries as above; they are read during the call only.  The device buffers must stay
+ *                           valid, and whatever produced them must be complete, until the wait.  On an error the op is not
+ *                           counted; shards already queued still run and the next wait drains them.
+ *   cnt_sharded_dev_wait    returns when every shard's stream is idle.  shard_ms (optional, ndev floats; zeros unless
+ *                           CNT_QUEUE_TIMED): each shard's device time over the whole batch since the previous wait.
+ *   cnt_sharded_dev_op_ms   CNT_QUEUE_TIMED: per-shard device time of op `op` (0-based) of the batch the last wait drained.
+ *   cnt_sharded_dev_close   waits, then frees the streams and events.
+ * A queue is used by one thread at a time; different queues are independent.  The calling thread's current device is
+ * restored by every call.  An unknown / closed handle is CNT_EINVAL. */
+#define CNT_QUEUE_TIMED 0x1u
+int cnt_sharded_dev_open(int ndev, unsigned flags, void **queue);
+int cnt_sharded_dev_close(void *queue);
+int cnt_sharded_dev_shards(void *queue, int *ndev);
+int cnt_n_to_bits_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags);
+int cnt_bits_to_n_sharded_dev_enqueue(void *queue, const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out, unsigned flags);
+int cnt_n_to_bits2_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags);
+int cnt_bits_to_n2_sharded_dev_enqueue(void *queue, const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out, unsigned flags);
+int cnt_sharded_dev_wait(void *queue, float *shard_ms);
+int cnt_sharded_dev_op_ms(void *queue, size_t op, float *shard_ms);
 
 /* ---- device-pointer tier: what the roofline metric measures ------------------- */
 /* Pointers are device memory on the calling thread's current device.  `stream`

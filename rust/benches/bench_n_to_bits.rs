@@ -98,6 +98,9 @@ fn bench_n_to_bits() {
         dest
     });
     group.bench_function("n_to_bits_hip", || n_to_bits_hip(&n));
+    // the `_into` idiom: the caller keeps the Vec, nothing is allocated or dropped inside the timed call
+    let mut words_into: Vec<u64> = Vec::new();
+    group.bench_function("n_to_bits_hip_into", || n_to_bits_hip_into(&n, &mut words_into));
 
     // device-resident: the 40 000 nucleotides already live in HBM, the words stay there
     let d_n = DeviceBuffer::from_slice(&n);
@@ -133,6 +136,8 @@ fn bench_bits_to_n() {
         group.bench_function("bits_to_n_clmul", || bits_to_n_clmul(&bits, len));
     }
     group.bench_function("bits_to_n_hip", || bits_to_n_hip(&bits, len));
+    let mut n_into: Vec<u8> = Vec::new();
+    group.bench_function("bits_to_n_hip_into", || bits_to_n_hip_into(&bits, len, &mut n_into));
 
     let d_bits = DeviceBuffer::from_slice(&bits);
     let d_n = DeviceBuffer::new(len);
@@ -175,6 +180,13 @@ fn bench_large(log2_sizes: &[u32]) {
         }
         group.bench_function(&format!("bits_to_n_hip/2^{} (host slices, PCIe inside)", log2), || bits_to_n_hip(&bits, len));
         assert_eq!(bits_to_n_hip(&bits, len), n, "round trip mismatch at 2^{}", log2);
+        // the same calls `_into` Vecs the caller keeps: no fresh pages, no munmap inside the timed call (the rows above
+        // allocate and drop their result inside it, like the reference's harness: benches/bench_n_to_bits.rs:6-7)
+        let mut words_into: Vec<u64> = Vec::new();
+        let mut n_into: Vec<u8> = Vec::new();
+        group.bench_function(&format!("n_to_bits_hip_into/2^{}", log2), || n_to_bits_hip_into(&n, &mut words_into));
+        group.bench_function(&format!("bits_to_n_hip_into/2^{}", log2), || bits_to_n_hip_into(&bits, len, &mut n_into));
+        assert!(words_into == bits && n_into == n, "_into mismatch at 2^{}", log2);
 
         let d_n = DeviceBuffer::from_slice(&n);
         let d_bits = DeviceBuffer::new(bits.len() * 8);

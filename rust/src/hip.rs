@@ -34,7 +34,15 @@ extern "C" {
     fn cnt_dev_download(h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     fn cnt_dev_sync(stream: *mut c_void) -> c_int;
     fn cnt_check_device_range(p: *const c_void, bytes: usize, device: c_int) -> c_int;
+    fn cnt_set_device(device: c_int) -> c_int;
     fn cnt_shutdown() -> c_int;
+    // multi-GPU device tier, enqueue-only: one library stream per shard, any number of ops queued ahead, one wait
+    fn cnt_sharded_dev_open(ndev: c_int, flags: c_uint, queue: *mut *mut c_void) -> c_int;
+    fn cnt_sharded_dev_close(queue: *mut c_void) -> c_int;
+    fn cnt_n_to_bits_sharded_dev_enqueue(queue: *mut c_void, d_n: *const *const c_void, n_len: *const usize, d_out: *const *mut c_void, out_words: *const usize, flags: c_uint) -> c_int;
+    fn cnt_bits_to_n_sharded_dev_enqueue(queue: *mut c_void, d_bits: *const *const c_void, words: *const usize, len: *const usize, d_out: *const *mut c_void, flags: c_uint) -> c_int;
+    fn cnt_sharded_dev_wait(queue: *mut c_void, shard_ms: *mut f32) -> c_int;
+    fn cnt_sharded_dev_op_ms(queue: *mut c_void, op: usize, shard_ms: *mut f32) -> c_int;
     // packed-domain operations (host tier): what the reference's README points to, on the packed words
     fn cnt_hamming(a: *const u64, b: *const u64, len: usize, distance: *mut u64) -> c_int;
     fn cnt_complement(bits: *const u64, len: usize, out: *mut u64) -> c_int;
@@ -44,6 +52,7 @@ extern "C" {
 
 const CNT_STRICT_LUT: c_uint = 1;
 const CNT_TAIL_LUT: c_uint = 4;
+const CNT_QUEUE_TIMED: c_uint = 1;
 
 fn check(status: c_int) {
     if status != 0 {
@@ -135,6 +144,55 @@ pub fn bits_to_n2_hip(bits: &[u64], len: usize) -> Vec<u8> {
         res.set_len(len);
     }
     res
+}
+
+/// `_into` forms: the same four codecs writing into a `Vec` the CALLER owns.  The `Vec` is cleared and its capacity
+/// reused (grown without zero-fill when too small), so a loop that times like the reference's harness does -- the result
+/// allocated AND dropped inside the timed call (`benches/bench_n_to_bits.rs:6-7`) -- pays neither the page faults of a
+/// fresh allocation nor the `munmap` of the dropped one: at 1 GiB that is 22 ms per decode instead of 74 ms
+/// (BENCH_r03 `host_tier`).  Same results, same panics as the returning forms.
+pub fn n_to_bits_hip_into(n: &[u8], res: &mut Vec<u64>) {
+    let words = unsafe { cnt_words_for(n.len()) };
+    res.clear();
+    res.reserve(words);
+    unsafe {
+        check(cnt_n_to_bits_ex(n.as_ptr(), n.len(), res.as_mut_ptr(), words, 0));
+        res.set_len(words);
+    }
+}
+
+pub fn bits_to_n_hip_into(bits: &[u64], len: usize, res: &mut Vec<u8>) {
+    if len > (bits.len() << 5) {
+        panic!("The length is greater than the number of nucleotides!");
+    }
+    res.clear();
+    res.reserve(len);
+    unsafe {
+        check(cnt_bits_to_n(bits.as_ptr(), bits.len(), len, res.as_mut_ptr()));
+        res.set_len(len);
+    }
+}
+
+pub fn n_to_bits2_hip_into(n: &[u8], res: &mut Vec<u64>) {
+    let words = unsafe { cnt_words2_for(n.len()) };
+    res.clear();
+    res.reserve(words);
+    unsafe {
+        check(cnt_n_to_bits2(n.as_ptr(), n.len(), res.as_mut_ptr(), words));
+        res.set_len(words);
+    }
+}
+
+pub fn bits_to_n2_hip_into(bits: &[u64], len: usize, res: &mut Vec<u8>) {
+    if len > bits.len() * 27 {
+        panic!("The length is greater than the number of nucleotides!");
+    }
+    res.clear();
+    res.reserve(len);
+    unsafe {
+        check(cnt_bits_to_n2(bits.as_ptr(), bits.len(), len, res.as_mut_ptr()));
+        res.set_len(len);
+    }
 }
 
 /// Contiguous-chunk sharding over `ndev` GPUs (0 = all visible); no collective.
@@ -293,6 +351,75 @@ pub fn bits_to_n_hip_dev(d_bits: &DeviceBuffer, words: usize, len: usize, d_out:
     unsafe { check(cnt_bits_to_n_dev(d_bits.ptr, words, len, d_out.ptr, 0, std::ptr::null_mut())) };
 }
 
+/// Make `device` the calling thread's current device (what `DeviceBuffer::new` allocates on).
+pub fn set_device(device: i32) {
+    unsafe { check(cnt_set_device(device)) };
+}
+
+/// Enqueue-only multi-GPU device tier: shard `k` is resident on device `k`; every `enqueue_*` call queues that codec
+/// call on every shard's own library stream and returns at once, `wait` drains all of them.  Queue the decode of step
+/// `s` behind its encode and step `s + 1` behind that, wait once: the devices run back to back while the host is a
+/// whole queue ahead (word `w` depends on nucleotides `[32w, 32w + 32)` only, `n_to_bits.rs:38-43`: no barrier).
+pub struct ShardedDevQueue {
+    handle: *mut c_void,
+    ndev: usize,
+}
+
+impl ShardedDevQueue {
+    /// `ndev` shards on devices `0..ndev`; `timed` records an event behind every op (`wait` / `op_ms` report device ms).
+    pub fn new(ndev: usize, timed: bool) -> ShardedDevQueue {
+        let mut handle: *mut c_void = std::ptr::null_mut();
+        unsafe { check(cnt_sharded_dev_open(ndev as c_int, if timed { CNT_QUEUE_TIMED } else { 0 }, &mut handle)) };
+        ShardedDevQueue { handle, ndev }
+    }
+
+    /// Queue the encode of every shard: `d_n[k]` holds `n_len[k]` nucleotides on device `k`, `d_out[k]` its words.
+    pub fn enqueue_n_to_bits(&mut self, d_n: &[&DeviceBuffer], n_len: &[usize], d_out: &[&DeviceBuffer]) {
+        assert!(d_n.len() == self.ndev && n_len.len() == self.ndev && d_out.len() == self.ndev);
+        let ins: Vec<*const c_void> = d_n.iter().map(|b| b.ptr as *const c_void).collect();
+        let outs: Vec<*mut c_void> = d_out.iter().map(|b| b.ptr).collect();
+        let caps: Vec<usize> = d_out.iter().map(|b| b.bytes / 8).collect();
+        for k in 0..self.ndev {
+            assert!(n_len[k] <= d_n[k].bytes);
+        }
+        unsafe { check(cnt_n_to_bits_sharded_dev_enqueue(self.handle, ins.as_ptr(), n_len.as_ptr(), outs.as_ptr(), caps.as_ptr(), 0)) };
+    }
+
+    /// Queue the decode of every shard: `len[k]` nucleotides from `words[k]` words of `d_bits[k]` into `d_out[k]`.
+    pub fn enqueue_bits_to_n(&mut self, d_bits: &[&DeviceBuffer], words: &[usize], len: &[usize], d_out: &[&DeviceBuffer]) {
+        assert!(d_bits.len() == self.ndev && words.len() == self.ndev && len.len() == self.ndev && d_out.len() == self.ndev);
+        for k in 0..self.ndev {
+            if len[k] > (words[k] << 5) {
+                panic!("The length is greater than the number of nucleotides!");
+            }
+            assert!(words[k] * 8 <= d_bits[k].bytes && len[k] <= d_out[k].bytes);
+        }
+        let ins: Vec<*const c_void> = d_bits.iter().map(|b| b.ptr as *const c_void).collect();
+        let outs: Vec<*mut c_void> = d_out.iter().map(|b| b.ptr).collect();
+        unsafe { check(cnt_bits_to_n_sharded_dev_enqueue(self.handle, ins.as_ptr(), words.as_ptr(), len.as_ptr(), outs.as_ptr(), 0)) };
+    }
+
+    /// Wait for everything queued; per-shard device milliseconds of the batch (zeros unless `timed`).
+    pub fn wait(&mut self) -> Vec<f32> {
+        let mut ms = vec![0f32; self.ndev];
+        unsafe { check(cnt_sharded_dev_wait(self.handle, ms.as_mut_ptr())) };
+        ms
+    }
+
+    /// Per-shard device milliseconds of op `op` of the batch the last `wait` drained (`timed` queues).
+    pub fn op_ms(&self, op: usize) -> Vec<f32> {
+        let mut ms = vec![0f32; self.ndev];
+        unsafe { check(cnt_sharded_dev_op_ms(self.handle, op, ms.as_mut_ptr())) };
+        ms
+    }
+}
+
+impl Drop for ShardedDevQueue {
+    fn drop(&mut self) {
+        unsafe { cnt_sharded_dev_close(self.handle) };
+    }
+}
+
 /// Debug aid for code that hands RAW device pointers to the `*_dev` entry points (a host pointer there is a GPU page
 /// fault when the kernel runs, not an error): true if `[p, p + bytes)` lies inside one allocation the current device
 /// can address.
@@ -354,6 +481,43 @@ mod tests {
         device_sync();
         assert_eq!(d_bits.to_vec::<u64>(1), vec![0xD8D8D8D8D8D8D8D8u64]);
         assert_eq!(d_back.to_vec::<u8>(32), n.to_vec());
+    }
+
+    #[test]
+    fn test_into_forms_reuse_the_callers_vec() {
+        let mut words: Vec<u64> = Vec::new();
+        n_to_bits_hip_into(b"ATCGATCGATCGATCGATCGATCGATCGATCG", &mut words);
+        assert_eq!(words, vec![0b1101100011011000110110001101100011011000110110001101100011011000]);
+        let cap = words.capacity();
+        n_to_bits_hip_into(b"ATCG", &mut words);
+        assert_eq!(words, vec![0b11011000]);
+        assert_eq!(words.capacity(), cap);
+        let mut n: Vec<u8> = Vec::new();
+        bits_to_n_hip_into(&vec![0b1101100011011000110110001101100011011000110110001101100011011000], 32, &mut n);
+        assert_eq!(n, b"ATCGATCGATCGATCGATCGATCGATCGATCG");
+        let mut w2: Vec<u64> = Vec::new();
+        n_to_bits2_hip_into(b"ATCGN", &mut w2);
+        assert_eq!(w2, vec![0b101110100011]);
+        bits_to_n2_hip_into(&w2, 5, &mut n);
+        assert_eq!(n, b"ATCGN");
+    }
+
+    #[test]
+    fn test_sharded_dev_queue_steps_ahead() {
+        set_device(0);
+        let n = b"ATCGATCGATCGATCGATCGATCGATCGATCG".repeat(1 << 10);
+        let d_n = DeviceBuffer::from_slice(&n);
+        let d_bits = DeviceBuffer::new(n.len() / 4);
+        let d_back = DeviceBuffer::new(n.len());
+        let mut q = ShardedDevQueue::new(1, true);
+        for _ in 0..3 {
+            q.enqueue_n_to_bits(&[&d_n], &[n.len()], &[&d_bits]);
+            q.enqueue_bits_to_n(&[&d_bits], &[n.len() / 32], &[n.len()], &[&d_back]);
+        }
+        let ms = q.wait();
+        assert!(ms[0] > 0.0 && q.op_ms(5)[0] > 0.0);
+        assert_eq!(d_back.to_vec::<u8>(n.len()), n);
+        assert!(d_bits.to_vec::<u64>(n.len() / 32).iter().all(|w| *w == 0xD8D8D8D8D8D8D8D8));
     }
 
     #[test]

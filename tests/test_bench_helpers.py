@@ -28,6 +28,8 @@ def test_stats_and_crossover():
 
     s = bench.stats_ms([3.0, 1.0, 2.0, 10.0])
     assert s == {"mean": 4.0, "median": 2.5, "min": 1.0, "max": 10.0, "n": 4}
+    s = bench.stats_ms([float(x) for x in range(1, 21)])  # from 10 samples on: p10 / p90 (profiles/r04_decode_spread.md)
+    assert s["p10"] == 3.0 and s["p90"] == 19.0 and s["n"] == 20 and s["min"] == 1.0 and s["max"] == 20.0
     host = {"2^12": {"n_to_bits_hip fresh out": 1.0, "bits_to_n_hip fresh out": 1.0},
             "2^20": {"n_to_bits_hip fresh out": 50.0, "bits_to_n_hip fresh out": 5.0},
             "2^30": {"n_to_bits_hip fresh out": 30.0, "bits_to_n_hip fresh out": 14.0}}

@@ -71,6 +71,42 @@ def test_single_gpu_line_small():
     assert abs(j["value"] - j["config"]["nt_per_step"] * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"]) / 1e9) < 0.01 * j["value"]
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_both_bench_forms_folded_onto_one_gpu(n):
+    """the two N > 1 forms of bench.py -- one rank per GPU under torch.distributed.run (the driver's) and
+    ONE process over N devices through the enqueue-only sharded tier -- with N = 4 and 8 shards folded onto this box's GPU:
+    same JSON contract, N rows, verified, and for the single-process form the fan-out's cost on the line
+    (`scaling_overhead_us`: wall per step over N shards minus N x the wall per step of shard 0 alone; <= 1 % of a 3.1-ms
+    kernel) with the host's enqueue time per step beside it."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CNT_BENCH_SHARE_GPU="1")
+    common = ["--gpus", str(n), "--steps", "20", "--warmup", "2", "--log2-nt", "26", "--shard-log2-nt", "27", "--cpu-seconds", "0"]
+    # (a) one process, N shards, everything queued, one wait
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _last_json(out.stdout)
+    assert j["n_gpus"] == n and j["verified"] is True and len(j["ranks"]) == n and j["devices"]["processes"] == 1
+    assert "enqueue-only" in j["config"]["launch"] and "ONE cnt_sharded_dev_wait" in j["config"]["launch"]
+    so = j["scaling_overhead"]
+    assert so["shards_per_device"] == n and so["per_step_us"] == j["scaling_overhead_us"]
+    assert so["per_step_us"] <= 31.0, so  # 1 % of a 3.1-ms kernel; folded shards overlap, so the number is usually negative
+    assert 0 < so["host_enqueue_us_per_step"] < 40.0 * n, so  # a few microseconds per launch, 2 n launches per step
+    assert all(r["encode_ms"]["n"] == 20 and r["encode_ms"]["p90"] >= r["encode_ms"]["p10"] > 0 for r in j["ranks"])
+    assert [r["first_nt"] for r in j["ranks"]] == [k << 26 for k in range(n)]
+    assert abs(j["value"] - j["config"]["nt_per_step"] * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"]) / 1e9) < 0.01 * j["value"]
+    # (b) the driver's form: N ranks (sharing cuda:0 over gloo here), barrier + max over ranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + common
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _last_json(out.stdout)
+    assert j["n_gpus"] == n and j["verified"] is True and [r["rank"] for r in j["ranks"]] == list(range(n))
+    assert len({r["pid"] for r in j["ranks"]}) == n and j["devices"]["control_plane"] == "gloo"
+    assert j["config"]["nt_per_step"] == 2 * n * (1 << 26) and j["configs4_sharded_encode"]["ranks_measured"] == n
+
+
 def test_two_rank_launch_path_shares_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -104,8 +140,8 @@ def test_two_rank_launch_path_shares_one_gpu():
 
 def test_gpus_n_without_a_launcher_is_one_process_over_n_devices():
     """`python bench.py --gpus N` launched plainly used to exit ("needs a torch.distributed.run
-    launch").  It now drives the N devices from ONE process through cnt_n_to_bits_sharded_dev / cnt_bits_to_n_sharded_dev
-    and prints the same JSON line.  On the 1-GPU box the N shards are folded onto cuda:0 (CNT_BENCH_SHARE_GPU=1 ->
+    launch").  It now drives the N devices from ONE process through the enqueue-only sharded tier (cnt_*_sharded_dev_enqueue,
+    one cnt_sharded_dev_wait for all steps) and prints the same JSON line.  On the 1-GPU box the N shards are folded onto cuda:0 (CNT_BENCH_SHARE_GPU=1 ->
     cnt_test_alias_devices); without that the shortage of devices is a clear error, not a wrong run."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-nt", "28", "--shard-log2-nt", "29"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, CNT_BENCH_SHARE_GPU="1"))
@@ -114,6 +150,7 @@ def test_gpus_n_without_a_launcher_is_one_process_over_n_devices():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified"] is True and j["steps"] == 3
     assert j["config"]["nt_per_gpu"] == 1 << 28 and j["config"]["nt_per_step"] == 2 * 2 * (1 << 28) and "single process" in j["config"]["launch"]
     assert j["devices"]["processes"] == 1 and j["devices"]["data_path_collective"] is None and j["devices"]["control_plane"] is None
+    assert j["scaling_overhead"]["shards_per_device"] == 2 and j["scaling_overhead"]["wall_ms_per_step_shard0_alone"] > 0
     rows = j["ranks"]
     assert [r["rank"] for r in rows] == [0, 1] and rows[0]["pid"] == rows[1]["pid"]
     assert rows[0]["first_nt"] == 0 and rows[1]["first_nt"] == 1 << 28 and all(r["nt"] == 1 << 28 for r in rows)
@@ -208,6 +245,12 @@ def test_cpu_baseline_and_host_tier_blocks():
     fo = h["fresh_over_reused_at_2^30"]
     for fn in ("n_to_bits_hip", "bits_to_n_hip"):
         assert 0.8 < fo[fn]["drop_outside"] <= fo[fn]["drop_inside"] * 1.25 and fo[fn]["drop_inside"] < 8.0, fo
+        assert 0.8 < fo[fn]["into"] < 1.3, fo  # the `_into` form IS the call into a reused output, through the mirror
+    tc = h["timing_conventions"]
+    assert set(tc) == {"what", "2^26", "2^28", "2^30"}
+    for fn in ("n_to_bits_hip", "bits_to_n_hip"):  # all three conventions on the line
+        row = tc["2^30"][fn]
+        assert row["into_us"] > 0 and row["drop_outside_us"] > 0 and row["drop_inside_us"] >= 0.8 * row["into_us"], row
     # roofline.traffic: HBM bytes per launch measured by THIS run (two rocprofv3 --pmc child passes, calibrated on
     # known-size probes) -- equal to the algorithmic bytes to well under 1 %: nothing is re-read
     for key in ("roofline", "roofline_decode"):

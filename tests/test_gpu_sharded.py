@@ -230,6 +230,87 @@ def test_device_resident_shards_match_the_oracle(L, oracle, alias, monkeypatch, 
     assert torch.cuda.current_device() == 0
 
 
+@pytest.mark.parametrize("ndev", [1, 2, 4, 8])
+def test_enqueue_only_queue_runs_steps_ahead_and_matches_the_oracle(L, oracle, alias, ndev):
+    """cnt_sharded_dev_open / *_enqueue / cnt_sharded_dev_wait: three encode -> decode steps queued without a wait in
+    between (each step over different inputs, decode k behind encode k on every shard's stream), one wait, every shard of
+    every step against the oracle; per-op device times come back for every op and add up to the batch time."""
+    import torch
+
+    from cute_nucleotides_amd import sharding
+
+    if ndev == 1:
+        L.cnt_test_alias_devices(0)
+    sizes = [(1 << 20) + 13, 0, 40000, 2048 * 5, 77, (1 << 19), 16384 * 3 + 1, 1][:ndev]
+    steps = 3
+    for five in (False, True):
+        gen = oracle.fill_random_acgtn if five else oracle.fill_random_acgt
+        enc = oracle.n_to_bits2_lut if five else oracle.n_to_bits_lut
+        unit = 27 if five else 32
+        host = [[gen(s, 900 + 10 * st + k) if s else np.empty(0, dtype=np.uint8) for k, s in enumerate(sizes)] for st in range(steps)]
+        d_in = [[torch.from_numpy(h).cuda() if h.size else torch.empty(0, dtype=torch.uint8, device="cuda") for h in row] for row in host]
+        d_pk = [[torch.zeros((s + unit - 1) // unit, dtype=torch.int64, device="cuda") for s in sizes] for _ in range(steps)]
+        d_out = [[torch.zeros(s, dtype=torch.uint8, device="cuda") for s in sizes] for _ in range(steps)]
+        torch.cuda.synchronize()
+        with sharding.DevQueue(ndev, timed=True) as q:
+            assert q.ndev == ndev
+            for st in range(steps):
+                q.n_to_bits(d_in[st], d_pk[st], five_letter=five)
+                q.bits_to_n(d_pk[st], sizes, d_out[st], five_letter=five)
+            total = q.wait()
+            per_op = [q.op_ms(i) for i in range(2 * steps)]
+            with pytest.raises(Exception):
+                q.op_ms(2 * steps)
+            for k, s in enumerate(sizes):
+                assert abs(sum(op[k] for op in per_op) - total[k]) < 1e-3 * max(1.0, total[k])
+                assert all(op[k] > 0.0 for op in per_op) or s == 0
+            # a second batch on the same queue reuses streams and events
+            q.n_to_bits(d_in[0], d_pk[1], five_letter=five)
+            assert len(q.wait()) == ndev
+        for st in range(steps):
+            for k, h in enumerate(host[st]):
+                want = enc(h) if h.size else np.empty(0, dtype=np.uint64)
+                got = d_pk[st][k].cpu().numpy().view(np.uint64) if st != 1 else None
+                if got is not None:
+                    assert np.array_equal(got, want), (five, ndev, st, k)
+                assert np.array_equal(d_out[st][k].cpu().numpy(), h), (five, ndev, st, k)
+        for k, h in enumerate(host[0]):  # the second batch's encode overwrote step 1's words with step 0's
+            want = enc(h) if h.size else np.empty(0, dtype=np.uint64)
+            assert np.array_equal(d_pk[1][k].cpu().numpy().view(np.uint64), want)
+    assert torch.cuda.current_device() == 0
+
+
+def test_enqueue_only_queue_error_paths(L, alias):
+    import torch
+
+    from cute_nucleotides_amd import _lib, sharding
+
+    q = ctypes.c_void_p()
+    assert L.cnt_sharded_dev_open(65, 0, ctypes.byref(q)) == _lib.CNT_ENODEV and not q.value
+    assert L.cnt_sharded_dev_open(2, 2, ctypes.byref(q)) == _lib.CNT_EINVAL  # unknown flag
+    assert L.cnt_sharded_dev_wait(ctypes.c_void_p(0x1234), None) == _lib.CNT_EINVAL  # not a live queue
+    assert L.cnt_sharded_dev_open(2, 0, ctypes.byref(q)) == 0 and q.value
+    a = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(256, dtype=torch.int64, device="cuda")
+    ptr = (ctypes.c_void_p * 2)(a.data_ptr(), a.data_ptr())
+    n_len = (ctypes.c_size_t * 2)(4096, 4096)
+    optr = (ctypes.c_void_p * 2)(o.data_ptr(), o.data_ptr() + 1024)
+    caps = (ctypes.c_size_t * 2)(128, 127)
+    # shard 1's capacity is short: shard 0 is already queued, the op is refused, the wait still drains shard 0
+    assert L.cnt_n_to_bits_sharded_dev_enqueue(q, ptr, n_len, optr, caps, 0) == _lib.CNT_ECAP
+    assert L.cnt_n_to_bits_sharded_dev_enqueue(q, None, n_len, optr, caps, 0) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_wait(q, None) == 0
+    ms = (ctypes.c_float * 2)()
+    assert L.cnt_sharded_dev_op_ms(q, 0, ms) == _lib.CNT_EINVAL  # not a timed queue
+    assert L.cnt_sharded_dev_close(q) == 0
+    assert L.cnt_sharded_dev_close(q) == _lib.CNT_EINVAL  # closed handles are refused, not dereferenced
+    assert L.cnt_n_to_bits_sharded_dev_enqueue(q, ptr, n_len, optr, caps, 0) == _lib.CNT_EINVAL
+    with sharding.DevQueue(2) as dq:
+        with pytest.raises(ValueError):
+            dq.n_to_bits([a], [o])  # one shard handed to a two-shard queue
+    assert torch.cuda.current_device() == 0
+
+
 def test_device_resident_shards_error_paths(L, oracle, alias):
     import torch
 
