@@ -83,6 +83,7 @@ SIGNATURES = {
     "cnt_chip_info": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "cnt_check_device_range": (_int, [ctypes.c_void_p, ctypes.c_size_t, _int]),
     "cnt_test_alias_devices": (_int, [_int]),
+    "cnt_test_advise_output": (_int, [_vp, _sz]),
 }
 
 _lib = None

@@ -486,6 +486,11 @@ int cnt_check_device_range(const void* p, size_t bytes, int device) {
 }
 
 int cnt_test_alias_devices(int on) { return g_alias_devices.exchange(on ? 1 : 0); }
+int cnt_test_advise_output(void* out, size_t bytes) {
+    if (!out) return CNT_EINVAL;
+    advise_huge_output(out, bytes);
+    return CNT_OK;
+}
 
 const char* cnt_tuning_name(const char* key, int value) {
     if (!key) return nullptr;

@@ -298,11 +298,12 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
- *   CNT_HOST_HUGEPAGE=0          do NOT madvise(MADV_HUGEPAGE) the 2-MiB-aligned interior of outputs >= 8 MiB.  The default
- *                                advises -- the one thing the library does to caller memory besides writing the result:
- *                                a fresh malloc'd output is then faulted in, and later freed by the caller, in 2-MiB
- *                                units (1-GiB decode into a fresh malloc: 150 -> 72-91 ms per call).  The advice changes
- *                                the caller's VMA flags for good (possible VMA split, huge-page RSS): set 0 if unwanted
+ *   CNT_HOST_HUGEPAGE=0          do NOT madvise(MADV_HUGEPAGE) any part of an output.  The default advises -- the one thing
+ *                                the library does to caller memory besides writing the result -- but ONLY the 2-MiB units of
+ *                                an output >= 8 MiB in which no page exists yet (one mincore() walk per call): a fresh malloc /
+ *                                Vec / np.empty is then faulted in, and later freed by the caller, in 2-MiB units (1-GiB
+ *                                decode into a fresh malloc: 150 -> 72-91 ms per call); a warm output (reused buffer, the
+ *                                `_into` forms) is never advised, its VMA flags and RSS stay as the caller made them
  *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
  *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy teams summed over all devices (default 32: 8 shards -> teams of
  *                                4); as above the threads that exist are up to twice that minus one per shard */
@@ -314,6 +315,10 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  * call -- no environment variable can make a production process shard onto the wrong device.
  * Returns the previous setting. */
 int cnt_test_alias_devices(int on);
+/* Runs the host tier's huge-page advice (see CNT_HOST_HUGEPAGE above) on [out, out + bytes) exactly as a host-tier call
+ * with that output would, without any device work: lets a box without a GPU check what the library does -- and does not
+ * do -- to caller memory (tests/test_hugepage_scope.py). */
+int cnt_test_advise_output(void *out, size_t bytes);
 
 #ifdef __cplusplus
 }
