@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""cnt_round_trip_dev at every kind of misalignment against the aligned call (one launch at any
+alignment, within 3 % of the aligned speed).  Offsets in bytes: input ASCII, packed words (multiples of 8), decoded ASCII.
+
+usage (GPU box): python bench/align_round_trip.py [--log2-nt 34]  -> one JSON line per offset triple"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cute_nucleotides_amd as cn  # noqa: E402
+from cute_nucleotides_amd import devutil  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log2-nt", type=int, default=34)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--queue", type=int, default=4)
+a = ap.parse_args()
+n = 1 << a.log2_nt
+pad = 16384
+b_in = torch.empty(n + pad, dtype=torch.uint8, device="cuda")
+b_pk = torch.empty(n // 32 + pad // 8, dtype=torch.int64, device="cuda")
+b_out = torch.empty(n + pad, dtype=torch.uint8, device="cuda")
+ref = torch.empty(n, dtype=torch.uint8, device="cuda")
+devutil.fill_random_acgt(ref, 0x5EED)
+ref_sum = None
+base = None
+for io, po, bo in ((0, 0, 0), (0, 0, 0), (1, 0, 0), (0, 8, 0), (0, 0, 1), (0, 0, 16), (0, 0, 64), (5, 8, 77), (64, 24, 4095), (127, 56, 1), (16, 0, 16), (100, 8, 2049)):
+    d_in, d_pk, d_out = b_in[io : io + n], b_pk[po // 8 : po // 8 + n // 32], b_out[bo : bo + n]
+    d_in.copy_(ref)
+    cn.round_trip_dev(d_in, out_bits=d_pk, out_n=d_out)
+    torch.cuda.synchronize()
+    s = devutil.checksum_words(d_pk.contiguous()) if po % 16 == 0 else None
+    ok = bool((d_out == ref).all()) if n <= (1 << 32) else (devutil.count_mismatch(ref, d_out) == 0 if bo % 16 == 0 else bool((d_out[: 1 << 30] == ref[: 1 << 30]).all()))
+    ms = []
+    for _ in range(a.rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.queue):
+            cn.round_trip_dev(d_in, out_bits=d_pk, out_n=d_out)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1) / a.queue)
+    med = statistics.median(ms)
+    if base is None and (io, po, bo) == (0, 0, 0) and ref_sum is not None:
+        base = med
+    if ref_sum is None:
+        ref_sum = s
+    row = {"in_off": io, "packed_off": po, "back_off": bo, "ms": round(med, 4), "min_ms": round(min(ms), 4), "GBs": round(2.25 * n / med / 1e6, 1),
+           "frac": round(2.25 * n / med / 1e6 / 8000, 4), "vs_aligned": round(med / base, 4) if base else None, "verified": ok and (s is None or s == ref_sum)}
+    print(json.dumps(row), flush=True)

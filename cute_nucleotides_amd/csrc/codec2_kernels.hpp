@@ -374,6 +374,104 @@ __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __rest
         round_trip_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * BLOCK + tid, (uint64_t)e.groups * BLOCK);
 }
 
+// FUSED round trip at ANY alignment of its three pointers, still one pass and one launch (round 4).  The tile is laid
+// on the WIDE store stream: tile t covers nucleotides [t0 + 4096 t, +4096) with d_back + t0 on a 128-B line (a 4-KiB
+// boundary for large buffers), so the 4 KiB of decoded ASCII leave as the aligned kernel's stores do.  The other two
+// streams take whatever phase that leaves them, and both are resolved on the PACKED CODES, which are 4x smaller than the
+// text (n_to_bits_window's trick, twice):
+//   * loads: the wave reads the 128-B-aligned window that covers its tile (`in` = d_n + t0 rounded down to a line,
+//     `phase` = the 0..127 bytes dropped, nine vectors of slack behind the tile), every lane packs the ALIGNED 16 bytes
+//     it loaded, and the code dwords go to the wave's LDS slab;
+//   * decoded stream: the 16 letters a lane stores come from code bits [2 * phase ..) of the slab -- two adjacent slab
+//     dwords funnel-shifted (v_alignbit_b32) -- and are spelled out from registers as in the aligned kernel;
+//   * packed stream: memory dword m holds nucleotides [16 m, 16 m + 16) of the CALLER's numbering; t0 is not a multiple
+//     of 16 in general, and the dword behind it is not on a 64-B segment of d_bits in general -- and packed stores that
+//     split 64-B segments between store instructions cost 11-18 % of the whole kernel (partial-segment writes,
+//     profiles/r04_align_round_trip_first.jsonl).  So tile t writes the 256 dwords that start at p0 + 256 t, p0 = the
+//     segment-aligned dword nearest to t0 (in front of it or behind it, at most 128 nucleotides away): a second funnel
+//     read of the same slab at its own phase.  The window starts at the line that holds the earlier of the two first
+//     nucleotides and carries up to 17 vectors of slack behind the tile for the later one.
+// The slab is the dynamic-LDS allocation that caps residency (one wave per workgroup: it is private).  Everything in front
+// of t0, behind the last tile, and the packed dword that straddles either border rides in the same launch as dword-granular
+// edge items (round_trip_edges_any below); the launcher keeps the window's reads inside the caller's buffer.
+struct RoundTripEdgesAny {
+    const uint8_t* n;
+    uint32_t* packed;  // the u64 words as dwords: dword d holds nucleotides [16 d, 16 d + 16)
+    uint8_t* back;
+    uint64_t n_len;
+    uint64_t t0, t1;    // the tiles write letters [t0, t1) ...
+    uint64_t p0, p1;    // ... and packed dwords [p0, p1), |16 p0 - t0| <= 128 + 15, p1 - p0 == (t1 - t0) / 16
+    uint64_t dwords;    // 2 x words: the zero-padded upper half of a last word with <= 16 nucleotides is written too
+    uint64_t lut_from;  // words >= lut_from take BYTE_LUT semantics (kNoLutWord: none)
+    uint32_t groups;
+};
+template <bool STRICT>
+__device__ __forceinline__ void round_trip_edges_any(const RoundTripEdgesAny& e, uint64_t idx, uint64_t stride) {
+    // dwords [0, h) and [f, dwords) hold a letter or a packed dword that the tiles do not write
+    const uint64_t h = max(e.p0, (e.t0 + 15) >> 4), f = min(e.p1, e.t1 >> 4);
+    const uint64_t items = h + (e.dwords - f);
+    for (uint64_t k = idx; k < items; k += stride) {
+        const uint64_t d = k < h ? k : f + (k - h);
+        const uint64_t i0 = d << 4;
+        const int m = i0 >= e.n_len ? 0 : ((e.n_len - i0) < 16 ? (int)(e.n_len - i0) : 16);
+        const bool lut = STRICT || (d >> 1) >= e.lut_from;
+        uint32_t code = 0;
+        for (int q = 0; q < m; q += 4) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q + j < m) x |= (uint32_t)e.n[i0 + q + j] << (8 * j);
+            if (lut) x = strict_filter(x);
+            code |= __builtin_amdgcn_ubfe(enc_gather(x & 0x06060606u), 19, 8) << (2 * q);
+        }
+        if (d < e.p0 || d >= e.p1) e.packed[d] = code;  // the tiles own [p0, p1)
+        for (int q = 0; q < m; ++q) {
+            const uint64_t i = i0 + q;
+            if (i < e.t0 || i >= e.t1) e.back[i] = (uint8_t)(0x47544341u >> (((code >> (2 * q)) & 3u) << 3));  // "ACTG"[code]
+        }
+    }
+}
+constexpr uint32_t kRoundTripAnyTile = 64 * 4 * 16;
+constexpr uint32_t kRoundTripAnySlackVecs = 25;  // 16-B vectors of the window a tile may read behind its 4 KiB (the launcher needs <= 17)
+constexpr uint32_t kRoundTripAnySlack = kRoundTripAnySlackVecs * 16;  // bytes a tile's window may read behind the tile's own end
+constexpr uint32_t kRoundTripAnySlab = 5 * 64 * 4;  // LDS bytes: four rows of code dwords + the slack row
+template <int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(kWave) void round_trip_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back,
+                                                          uint32_t n_tiles, uint32_t phase, uint32_t phase2, uint32_t xs, RoundTripEdgesAny e) {
+    constexpr uint32_t TILE = kRoundTripAnyTile;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE, TILE + kRoundTripAnySlack);
+    const __amdgpu_buffer_rsrc_t rpk = rsrc_of(packed + t * (TILE / 4), TILE / 4);
+    const __amdgpu_buffer_rsrc_t rbk = rsrc_of(back + t * TILE, TILE);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q = phase >> 4, sh = (phase & 15) << 1;
+    const uint32_t q2 = phase2 >> 4, sh2 = (phase2 & 15) << 1;  // both phases <= 127 + 143
+    u32x4 v[5];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * kWave + lane) * 16, 0, LAUX));
+    // lanes 0..max(q, q2)+1 fetch the vectors behind the tile that the two funnels reach; the others aim past the
+    // descriptor's range (zeros, no memory access)
+    v[4] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane <= max(q, q2) + 1 ? (4 * kWave + lane) * 16 : 0xFFFFFF00u, 0, LAUX));
+#pragma unroll
+    for (int u = 0; u < 5; ++u) residency_pad[u * kWave + lane] = enc16<STRICT>(v[u]);
+    wave_lds_fence();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t j = u * kWave + lane;
+        const uint32_t cb = __builtin_amdgcn_alignbit(residency_pad[j + q + 1], residency_pad[j + q], sh);      // letters [t0 + 16 j, +16)
+        const uint32_t cp = __builtin_amdgcn_alignbit(residency_pad[j + q2 + 1], residency_pad[j + q2], sh2);  // packed dword p0 + j
+        __builtin_amdgcn_raw_buffer_store_b32(cp, rpk, j * 4, 0, SAUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(cb)), rbk, j * 16, 0, SAUX);
+    }
+    if (blockIdx.x + e.groups >= n_tiles)
+        round_trip_edges_any<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * kWave + lane, (uint64_t)e.groups * kWave);
+}
+// inputs shorter than a tile + slack: the edge body alone, one launch
+template <bool STRICT>
+__global__ __launch_bounds__(kBlock) void round_trip_generic(RoundTripEdgesAny e) {
+    round_trip_edges_any<STRICT>(e, blockIdx.x * (uint64_t)kBlock + threadIdx.x, (uint64_t)gridDim.x * kBlock);
+}
+
 // LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,
 // packs to U dwords per lane, parks them in its private LDS slab in output order
 // (ds_write_b32, conflict-free), reads back 16 B per lane (ds_read_b128) and

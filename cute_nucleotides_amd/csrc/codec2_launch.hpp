@@ -262,6 +262,26 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
     }
 }
 
+// The any-alignment fused round trip (codec2_kernels.hpp, round_trip_window): `base` = d_n + t0 rounded down to 128 B,
+// the window's first byte (128-B aligned), `phase` / `phase2` = where nucleotide t0 / 16 e.p0 sit in it, `packed` = the
+// (64-B aligned) address of dword e.p0, `back` = d_back + t0 (line-aligned).
+// Same shape, policies and residency cap as the aligned kernel; the cap's dynamic LDS doubles as the 1280-B exchange slab.
+template <bool STRICT>
+void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap,
+                           RoundTripEdgesAny e, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(64) / 2;
+    const uint32_t lds = std::max(lds_for_cap(cap), kRoundTripAnySlab);
+    const uint32_t xs = xcd_shift();
+    const uint64_t items = std::max<uint64_t>(e.p0, (e.t0 + 15) >> 4) + (e.dwords - std::min<uint64_t>(e.p1, e.t1 >> 4));
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+        const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        e.groups = first + n_tiles == total_tiles ? edge_groups(items, 64, n_tiles) : 0u;  // the edges ride in the last launch
+        hipLaunchKernelGGL((round_trip_window<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+                           base + first * kRoundTripAnyTile, packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile,
+                           (uint32_t)n_tiles, phase, phase2, xs, e);
+    }
+}
+
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},  // 0: default (round 3; rounds 1-2: variant 35)

@@ -199,8 +199,10 @@ int cnt_n_to_bits2_dev(const void *d_n, size_t n_len, void *d_out, size_t out_wo
  * d_back = bits_to_n(d_bits, n_len) -- i.e. the canonical spelling of the input: upper case,
  * U -> T, and with CNT_STRICT_LUT every byte outside the alphabet -> 'A' (n_to_bits.rs:8-21
  * followed by :23-30) -- reading the ASCII once and never re-reading the packed words (2.25
- * instead of 2.5 bytes of HBM traffic per nucleotide).  d_back holds n_len bytes.  Full speed needs
- * all three pointers 128-byte aligned; otherwise the call is the two calls above in sequence. */
+ * instead of 2.5 bytes of HBM traffic per nucleotide).  d_back holds n_len bytes.  ONE launch at any size and any
+ * alignment of d_n and d_back (d_bits: 8 bytes, as everywhere): off the 128-byte grid the tiles are laid on the decoded
+ * stream's lines and the other two streams' phases are resolved on the packed codes (within a few percent of the
+ * aligned speed). */
 int cnt_round_trip_dev(const void *d_n, size_t n_len, void *d_bits, size_t out_words, void *d_back, unsigned flags, void *stream);
 int cnt_bits_to_n2_dev(const void *d_bits, size_t words, size_t len, void *d_out, unsigned flags, void *stream);
 

@@ -487,8 +487,8 @@ def test_device_tier_is_graph_capturable(cn, oracle, torch_cuda, tuning, small_n
 # ---- fused round trip (BASELINE.json configs[3]) ----------------------------------------------
 @pytest.mark.parametrize("strict", [False, True])
 def test_fused_round_trip_matches_two_calls(cn, oracle, torch_cuda, strict):
-    """cnt_round_trip_dev == n_to_bits followed by bits_to_n, for aligned (fused tiles) and misaligned
-    (fallback) pointers, ragged sizes, any bytes under CNT_STRICT_LUT; guard bytes around both outputs."""
+    """cnt_round_trip_dev == n_to_bits followed by bits_to_n, for aligned (round_trip_stream) and misaligned
+    (round_trip_window / the edge body alone) pointers, ragged sizes, any bytes under CNT_STRICT_LUT; guard bytes around both outputs."""
     torch = torch_cuda
     rng = np.random.default_rng(41)
     for n_len in (1, 31, 2047, 2048, 2049, 40000, 2048 * 37 + 5, (1 << 20) + 13):
@@ -509,6 +509,50 @@ def test_fused_round_trip_matches_two_calls(cn, oracle, torch_cuda, strict):
             assert np.array_equal(b[back_off : back_off + n_len], want_back), (n_len, in_off, bits_off, back_off)
             assert (p[:bits_off] == -1).all() and (p[bits_off + words :] == -1).all()
             assert (b[:back_off] == 0x2A).all() and (b[back_off + n_len :] == 0x2A).all()
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_fused_round_trip_alignment_matrix(cn, oracle, torch_cuda, strict):
+    """cnt_round_trip_dev at EVERY combination of input byte phase, packed-word phase and decoded-output
+    byte phase (the window kernel: tiles on the decoded stream's lines, both other phases resolved on the packed codes),
+    sizes on both sides of the tile + slack boundaries and around 2^20 (4-KiB grain), guard values around both outputs:
+    bit-exact against n_to_bits_lut / bits_to_n_lut and nothing written outside.  tail_lut on arbitrary bytes too."""
+    torch = torch_cuda
+    sizes = [4096 + 399, 4096 + 400, 4096 + 401, 4096 + 128 + 400 + 1, 3 * 4096 + 77, 40000, 100003, (1 << 20) + 4096 + 13]
+    rng = np.random.default_rng(61)
+    big = rng.integers(0, 256, max(sizes), dtype=np.uint8) if strict else _rand_valid(max(sizes), 62)
+    ibuf = torch.zeros(big.size + 256, dtype=torch.uint8, device="cuda")
+    pbuf = torch.empty(big.size // 32 + 64, dtype=torch.int64, device="cuda")
+    bbuf = torch.empty(big.size + 8192 + 512, dtype=torch.uint8, device="cuda")
+    in_offs = [0, 1, 5, 15, 16, 17, 63, 64, 100, 127]
+    back_offs = [0, 1, 3, 15, 16, 33, 64, 127, 128, 2049, 4095]
+    for n_len in sizes:
+        n = big[:n_len]
+        want_bits = oracle.n_to_bits_lut(n)
+        want_back = oracle.bits_to_n_lut(want_bits, n_len)
+        words = want_bits.size
+        for io in in_offs if n_len < (1 << 20) else [0, 5, 64]:
+            view = ibuf[io : io + n_len]
+            view.copy_(torch.from_numpy(n))
+            for po in (0, 1, 3, 8, 15):
+                for bo in back_offs if n_len < 100003 else [0, 1, 33, 2049, 4095]:
+                    pbuf.fill_(-1)
+                    bbuf.fill_(0x2A)
+                    cn.round_trip_dev(view, out_bits=pbuf[8 + po : 8 + po + words], out_n=bbuf[128 + bo : 128 + bo + n_len], strict_lut=strict)
+                    p, b = pbuf.cpu().numpy(), bbuf.cpu().numpy()
+                    assert (p[: 8 + po] == -1).all() and (p[8 + po + words :] == -1).all(), (n_len, io, po, bo)
+                    assert (b[: 128 + bo] == 0x2A).all() and (b[128 + bo + n_len :] == 0x2A).all(), (n_len, io, po, bo)
+                    assert np.array_equal(p[8 + po : 8 + po + words].view(np.uint64), want_bits), (n_len, io, po, bo)
+                    assert np.array_equal(b[128 + bo : 128 + bo + n_len], want_back), (n_len, io, po, bo)
+    if not strict:  # CNT_TAIL_LUT through the window kernel: the SIMD encoders to the letter on arbitrary bytes
+        raw = rng.integers(0, 256, 100003, dtype=np.uint8)
+        view = ibuf[7 : 7 + raw.size]
+        view.copy_(torch.from_numpy(raw))
+        bits, back = cn.round_trip_dev(view, out_bits=pbuf[1 : 1 + (raw.size + 31) // 32], out_n=bbuf[3 : 3 + raw.size], tail_lut=True)
+        want = oracle.n_to_bits_bitextract(raw[: raw.size // 32 * 32])
+        tail = oracle.n_to_bits_lut(raw[raw.size // 32 * 32 :])
+        assert np.array_equal(bits.cpu().numpy().view(np.uint64), np.concatenate([want, tail]))
+        assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(np.concatenate([want, tail]), raw.size))
 
 
 def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
@@ -792,9 +836,18 @@ def test_any_size_and_alignment_is_one_launch(cn, oracle, torch_cuda, tuning):
     out.zero_()
     assert _kernel_nodes_of(torch, lambda: cn.round_trip_dev(view, out_bits=packed, out_n=out)) == 1
     assert np.array_equal(packed.cpu().numpy().view(np.uint64), want) and np.array_equal(out.cpu().numpy(), want_back)
+    # ... and at ANY alignment of its three pointers (it used to degrade to two launches off the 128-B grid)
+    for io, po, oo in ((5, 0, 77), (64, 1, 4095), (127, 7, 1), (0, 3, 0), (0, 0, 16), (1, 0, 0)):
+        view, packed, out = ibuf[io : io + n_len], pbuf[po : po + words], obuf[oo : oo + n_len]
+        view.copy_(torch.from_numpy(host))
+        packed.zero_()
+        out.zero_()
+        assert _kernel_nodes_of(torch, lambda: cn.round_trip_dev(view, out_bits=packed, out_n=out)) == 1, (io, po, oo)
+        assert np.array_equal(packed.cpu().numpy().view(np.uint64), want) and np.array_equal(out.cpu().numpy(), want_back), (io, po, oo)
     # shorter than one tile: the generic kernel alone, also one launch
     small = ibuf[3 : 3 + 1000]
     assert _kernel_nodes_of(torch, lambda: cn.n_to_bits_dev(small, out=pbuf[:32])) == 1
+    assert _kernel_nodes_of(torch, lambda: cn.round_trip_dev(small, out_bits=pbuf[:32], out_n=obuf[9 : 9 + 1000])) == 1
 
 
 # ---- BASELINE.json configs[4]: every rank's shard of the 256 GiB job, at its GLOBAL offset ---------------------------

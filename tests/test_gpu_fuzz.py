@@ -177,10 +177,17 @@ def test_fused_and_packed_ops_fuzz(oracle, seed):
         buf = torch.zeros(n_len + 256, dtype=torch.uint8, device="cuda")
         view = buf[off : off + n_len]
         view.copy_(torch.from_numpy(n))
-        bits, back = cn.round_trip_dev(view, strict_lut=strict)
+        # all three pointers at random phases (round_trip_window off the 128-B grid), guards around both outputs
+        po_w, bo = int(rng.integers(0, 17)), int(rng.choice([0, 0, 128, 1, 16, 77, 4095]))
+        words = (n_len + 31) // 32
+        pbuf = torch.full((words + po_w + 8,), -1, dtype=torch.int64, device="cuda")
+        bbuf = torch.full((n_len + bo + 64,), 0x2A, dtype=torch.uint8, device="cuda")
+        bits, back = cn.round_trip_dev(view, out_bits=pbuf[po_w : po_w + words], out_n=bbuf[bo : bo + n_len], strict_lut=strict)
         want = oracle.n_to_bits_lut(n)
-        assert np.array_equal(bits.cpu().numpy().view(np.uint64), want), (seed, n_len, off, strict)
-        assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(want, n_len)), (seed, n_len, off, strict)
+        assert np.array_equal(bits.cpu().numpy().view(np.uint64), want), (seed, n_len, off, po_w, bo, strict)
+        assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(want, n_len)), (seed, n_len, off, po_w, bo, strict)
+        pb, bb = pbuf.cpu().numpy(), bbuf.cpu().numpy()
+        assert (pb[:po_w] == -1).all() and (pb[po_w + words :] == -1).all() and (bb[:bo] == 0x2A).all() and (bb[bo + n_len :] == 0x2A).all(), (seed, n_len)
         other = oracle.n_to_bits_lut(alpha[rng.integers(0, 10, n_len)])
         d_other = torch.from_numpy(other.view(np.int64)).cuda()
         assert int(po.hamming_dev(bits, d_other, n_len).item()) == oracle.hamming(want, other, n_len), (seed, n_len)
