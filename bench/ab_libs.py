@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--libs", nargs="+", default=["cur=cute_nucleotides_amd/libcute_nt_hip.so"])
+ap.add_argument("--libs", nargs="+", default=["cur=bench/libcute_nt_hip_lab.so"],
+                help="name=path ...; --decode-variants / --encode-variants need a LAB build first in the list (the product library has no cnt_set_tuning)")
 ap.add_argument("--log2-nt", type=int, default=34)
 ap.add_argument("--minus", type=int, default=0, help="subtract this many nt (ragged sizes)")
 ap.add_argument("--rounds", type=int, default=10)

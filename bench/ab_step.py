@@ -13,6 +13,10 @@ import torch  # noqa: E402
 
 import cute_nucleotides_amd as cn  # noqa: E402
 from cute_nucleotides_amd import devutil  # noqa: E402
+from cute_nucleotides_amd import _lib as _cnt_lib  # noqa: E402
+
+_cnt_lib.use_lab_build()  # this script selects kernel variants: bench/libcute_nt_hip_lab.so, not the product library
+
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)

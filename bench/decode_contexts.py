@@ -7,6 +7,10 @@ sys.path.insert(0, "/root/repo")
 import torch
 import cute_nucleotides_amd as cn
 from cute_nucleotides_amd import devutil
+from cute_nucleotides_amd import _lib as _cnt_lib  # noqa: E402
+
+_cnt_lib.use_lab_build()  # this script selects kernel variants: bench/libcute_nt_hip_lab.so, not the product library
+
 n = 1 << 34
 d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
 d_p = torch.empty(n // 32, dtype=torch.int64, device="cuda")

@@ -10,6 +10,10 @@ import torch  # noqa: E402
 
 import cute_nucleotides_amd as cn  # noqa: E402
 from cute_nucleotides_amd import devutil  # noqa: E402
+from cute_nucleotides_amd import _lib as _cnt_lib  # noqa: E402
+
+_cnt_lib.use_lab_build()  # this script selects kernel variants: bench/libcute_nt_hip_lab.so, not the product library
+
 
 for small, n_len in ((0, 40000), (1 << 17, 40000), (0, 100000), (1 << 17, 100000), (0, 1 << 20)):
     devutil.set_tuning("small_nt", small)

@@ -3,7 +3,7 @@
 per kernel, from the gfx950 assembly of the library's one translation unit (no GPU needed: hipcc cross-compiles).
 
     python bench/isa_digest.py            # print the digest
-    python bench/isa_digest.py --write    # refresh profiles/r03_isa_digest.txt
+    python bench/isa_digest.py --write    # refresh profiles/r04_isa_digest.txt
 
 tests/test_isa_digest.py (CPU box, -m "not gpu") regenerates the digest, compares it with the committed file and
 asserts the properties DESIGN.md argues from: streaming loads with `nt`, write-through stores `sc0 sc1 nt`,
@@ -19,7 +19,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cute_nucleotides_amd", "csrc", "cute_nt.hip")
-DIGEST = os.path.join(ROOT, "profiles", "r03_isa_digest.txt")
+DIGEST = os.path.join(ROOT, "profiles", "r04_isa_digest.txt")
+DIGEST_R03 = os.path.join(ROOT, "profiles", "r03_isa_digest.txt")  # round 3's: the kernels both rounds ship must not have moved
 
 # the kernels the default paths launch (demangled prefix up to the template arguments' closing bracket)
 SHIPPED = [
@@ -28,6 +29,7 @@ SHIPPED = [
     ("decode", "void cnt::bits_to_n_stream<64, 4, 4, 0, 19>"),
     ("decode, any output phase", "void cnt::bits_to_n_shifted<64, 4, 4, 0, 19>"),
     ("fused round trip", "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>"),
+    ("fused round trip, any alignment", "void cnt::round_trip_window<1, 2, 19, false>"),
     ("5-letter encode", "void cnt::n_to_bits2_wave<1, 2, 2, 16, false, 1>"),
     ("5-letter decode", "void cnt::bits_to_n2_wave<1, 2, 0, 19, 4>"),
     ("hamming", "void cnt::hamming_persist<8>"),
@@ -46,12 +48,13 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def assembly():
-    """demangled gfx950 assembly of the library's device code, same flags as cute_nucleotides_amd/build.py"""
+def assembly(lab=False):
+    """demangled gfx950 assembly of the library's device code, same flags as cute_nucleotides_amd/build.py (the PRODUCT
+    build; lab=True adds -DCNT_LAB_VARIANTS)"""
     with tempfile.TemporaryDirectory(prefix="cnt_isa_") as tmp:
         out = os.path.join(tmp, "cute_nt.s")
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", out, SRC],
-                              stderr=subprocess.DEVNULL)
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + (["-DCNT_LAB_VARIANTS"] if lab else []) +
+                              ["-o", out, SRC], stderr=subprocess.DEVNULL)
         cxxfilt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
         if not os.path.exists(cxxfilt):
             cxxfilt = "c++filt"

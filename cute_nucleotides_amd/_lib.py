@@ -8,6 +8,10 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcute_nt_hip.so")
+# The LAB build of the same sources (-DCNT_LAB_VARIANTS: every measured kernel variant + cnt_set_tuning), under bench/ and
+# never loaded unless a bench script or a test asks for it with use_lab_build(): the product library has no run-time kernel
+# selection (cnt_set_tuning answers CNT_EINVAL there).
+LAB_LIB_PATH = os.path.join(os.path.dirname(HERE), "bench", "libcute_nt_hip_lab.so")
 
 CNT_OK, CNT_EINVAL, CNT_ECAP, CNT_ELEN, CNT_ENODEV, CNT_ERANGE = 0, 1, 2, 3, 4, 5
 CNT_STRICT_LUT = 0x1
@@ -86,7 +90,8 @@ SIGNATURES = {
     "cnt_test_advise_output": (_int, [_vp, _sz]),
 }
 
-_lib = None
+_libs = {}          # "product" / "lab" -> loaded CDLL
+_active = "product"
 
 
 class CuteNtError(RuntimeError):
@@ -95,23 +100,37 @@ class CuteNtError(RuntimeError):
         self.status = status
 
 
+def use_lab_build(on=True):
+    """BENCH / TEST SUPPORT: make every wrapper of this package call bench/libcute_nt_hip_lab.so (built on demand) instead of
+    the product library, for this process, until switched back.  Returns the previous setting.  Both libraries can be
+    loaded side by side; each keeps its own streams and scratch."""
+    global _active
+    prev = _active == "lab"
+    _active = "lab" if on else "product"
+    return prev
+
+
+def is_lab_build():
+    return _active == "lab"
+
+
 def lib():
-    """Load the HIP library (once).  Raises if it is not built -- no CPU fallback exists."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    """Load the active HIP library (once per build).  Raises if it is not built -- no CPU fallback exists."""
+    if _active not in _libs:
+        path = LAB_LIB_PATH if _active == "lab" else LIB_PATH
+        if not os.path.exists(path):
             # not built yet on this box: compile it (hipcc, gfx950) rather than give up -- this is
             # still the HIP library, never a CPU substitute; without hipcc the import fails below
             try:
                 from . import build as _build
 
-                _build.build()
+                (_build.build_lab if _active == "lab" else _build.build)()
             except Exception as exc:  # noqa: BLE001
-                raise ImportError("%s is missing and could not be built: %s" % (LIB_PATH, exc)) from exc
-        if not os.path.exists(LIB_PATH):
+                raise ImportError("%s is missing and could not be built: %s" % (path, exc)) from exc
+        if not os.path.exists(path):
             raise ImportError(
-                "%s is missing: build it with `python -m cute_nucleotides_amd.build` "
-                "(or __graft_entry__.build()); this package has no CPU fallback" % LIB_PATH
+                "%s is missing: build it with `python -m cute_nucleotides_amd.build%s` "
+                "(or __graft_entry__.build()); this package has no CPU fallback" % (path, " --lab" if _active == "lab" else "")
             )
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname
         # libamdhip64.so.7) and loads it by file name, so it must be in the process BEFORE this
@@ -119,7 +138,7 @@ def lib():
         # Loading in the other order maps two runtimes and the second one sees no device.
         import torch  # noqa: F401  (device memory + streams plumbing; must precede the CDLL)
 
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         _assert_single_hip_runtime()
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here = ABI mismatch, fail loudly
@@ -127,8 +146,8 @@ def lib():
             f.argtypes = args
         if L.cnt_abi_version() != 1:
             raise ImportError("libcute_nt_hip ABI version mismatch")
-        _lib = L
-    return _lib
+        _libs[_active] = L
+    return _libs[_active]
 
 
 def _assert_single_hip_runtime():

@@ -10,6 +10,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcute_nt_hip.so")
+# the same translation unit with -DCNT_LAB_VARIANTS: every measured kernel variant + the process-global tuning knobs that
+# select them (cnt_set_tuning).  Bench / test infrastructure, kept out of the product package on purpose.
+LAB_LIB = os.path.join(os.path.dirname(HERE), "bench", "libcute_nt_hip_lab.so")
 SOURCES = ["cute_nt.hip"]
 # every file the one translation unit includes: a non-forced build() must notice an edit to any of them
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))) + [os.path.join("..", "..", "include", "cute_nt.h")]
@@ -23,26 +26,45 @@ def hipcc_path():
     return p
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Build the library if missing or older than its sources; returns its path."""
-    if not force and not _stale():
-        return LIB
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+def _compile(lib, defines, verbose):
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC"] + defines + \
+          ["-o", lib + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
+
+
+def build(force=False, verbose=False):
+    """Build the PRODUCT library (defaults + the any-alignment kernels, no run-time kernel selection) if missing or older
+    than its sources; returns its path."""
+    if not force and not _stale():
+        return LIB
+    return _compile(LIB, [], verbose)
+
+
+def build_lab(force=False, verbose=False):
+    """Build bench/libcute_nt_hip_lab.so: the same sources with -DCNT_LAB_VARIANTS (all kernel variants + cnt_set_tuning)."""
+    if not force and not _stale(LAB_LIB):
+        return LAB_LIB
+    return _compile(LAB_LIB, ["-DCNT_LAB_VARIANTS"], verbose)
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    import time
+
+    t0 = time.time()
+    print(build(force=True, verbose=True), "%.1f s" % (time.time() - t0))
+    if "--lab" in sys.argv:
+        t0 = time.time()
+        print(build_lab(force=True, verbose=True), "%.1f s" % (time.time() - t0))

@@ -1,8 +1,11 @@
 // codec2_launch.hpp -- the kernel-variant tables of the 2-bit codec and their launchers.
 //
-// Variant 0 of each direction is the shipped default (the measured best on MI355X at the
-// metric size, 2^34 nt); the others are kept selectable through cnt_set_tuning() so the A/B
-// numbers in DESIGN.md can be re-measured by bench/sweep_variants.py on any box.
+// Variant 0 of each direction is the shipped default (the measured best on MI355X at the metric size, 2^34 nt) and the
+// ONLY one the product library (libcute_nt_hip.so) contains.  Everything else -- the other shapes, cache policies, tile
+// maps and residency caps that the A/B numbers in profiles/ were measured with, and the process-global knobs that select
+// them -- is compiled only with -DCNT_LAB_VARIANTS, into bench/libcute_nt_hip_lab.so (cute_nucleotides_amd/build.py
+// build_lab()): the product has no mutable kernel selection, like the reference's pure functions over immutable tables
+// (n_to_bits.rs:8,23).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -70,8 +73,9 @@ inline const ChipInfo& chip_info() {  // of the calling thread's current device
     return table[dev];
 }
 
-// log2 of the XCD count the block -> tile maps are built for: the device's, unless the tuning key "xcd_shift" overrides it
-// (A/B runs, and the test that walks every value a partition mode could produce: the maps must be bijections for ANY value)
+// log2 of the XCD count the block -> tile maps are built for: the device's.  Lab build: the tuning key "xcd_shift" overrides it
+// (A/B runs, and the test that walks every value a partition mode could produce: the maps must be bijections for ANY value).
+#ifdef CNT_LAB_VARIANTS
 inline std::atomic<int>& xcd_shift_override() {
     static std::atomic<int> v{-1};
     return v;
@@ -80,6 +84,9 @@ inline uint32_t xcd_shift() {
     const int o = xcd_shift_override().load(std::memory_order_relaxed);
     return o >= 0 ? (uint32_t)o : chip_info().xcd_shift;
 }
+#else
+inline uint32_t xcd_shift() { return chip_info().xcd_shift; }
+#endif
 
 // dynamic-LDS bytes that let `cap` workgroups (and no more) fit in a CU's LDS (160 KiB on gfx950)
 inline uint32_t lds_for_cap(uint32_t cap) { return cap ? (chip_info().lds_per_cu / cap) / 256u * 256u : 0u; }
@@ -93,6 +100,7 @@ inline uint32_t lds_pad_for_cap(uint32_t cap, uint32_t static_bytes) {
 // ---- encode -------------------------------------------------------------------------
 constexpr VariantDesc kEncodeVariants[] = {
     {"stream B=64 U=2 plain order ld=nt st=sc0|sc1|nt, 23 wg/CU", 64 * 2 * 16, 64, 23},  // 0: default (round 3; rounds 1-2: variant 17)
+#ifdef CNT_LAB_VARIANTS
     {"stream B=256 U=1 ld=nt st=sc1", 256 * 1 * 16, 256, 0},              // 1
     {"stream B=512 U=1 ld=sc0|nt st=sc1", 512 * 1 * 16, 512, 0},          // 2
     {"stream B=256 U=4 ld=nt st=nt", 256 * 4 * 16, 256, 0},               // 3: the first shape tried
@@ -126,6 +134,7 @@ constexpr VariantDesc kEncodeVariants[] = {
     {"stream B=64 U=2 plain order ld=nt st=sc1, 23 wg/CU", 64 * 2 * 16, 64, 23},             // 25
     {"stream B=128 U=2 plain order ld=nt st=sc0|sc1|nt, 11 wg/CU", 128 * 2 * 16, 128, 11},   // 26
     {"stream B=64 U=4 plain order ld=nt st=sc0|sc1|nt, 12 wg/CU", 64 * 4 * 16, 64, 12},      // 27
+#endif
 };
 constexpr int kNumEncodeVariants = sizeof(kEncodeVariants) / sizeof(kEncodeVariants[0]);
 
@@ -135,16 +144,22 @@ inline unsigned grid_of(uint64_t n_tiles) { return (unsigned)(n_tiles > 0x7FFFFF
 // ("invalid configuration argument"): 2^36 nt in 2 KiB tiles is 2^25 workgroups of
 // 64 = 2^31 threads.  Large buffers are therefore cut into several launches of at
 // most this many tiles (a multiple of 64, so every XCD-group permutation stays whole).
-// The tuning key "launch_tiles" lowers the limit (a multiple of 64; 0 = the hardware's) so that the tests can walk every
-// launcher's several-launch loop -- and the rule that the edges ride in the LAST launch only -- at sizes of a few MiB.
+// Lab build: the tuning key "launch_tiles" lowers the limit (a multiple of 64; 0 = the hardware's) so that the tests can walk
+// every launcher's several-launch loop -- and the rule that the edges ride in the LAST launch only -- at sizes of a few MiB.
+#ifdef CNT_LAB_VARIANTS
 inline std::atomic<int>& launch_tiles_override() {
     static std::atomic<int> v{0};
     return v;
 }
+#endif
 inline uint64_t max_tiles_per_launch(int block) {
     const uint64_t hw = ((0x7FFFFFFFull / (uint64_t)block) / 64) * 64;
+#ifdef CNT_LAB_VARIANTS
     const int o = launch_tiles_override().load(std::memory_order_relaxed);
     return o > 0 && (uint64_t)o < hw ? (uint64_t)o : hw;
+#else
+    return hw;
+#endif
 }
 // how many of a launch's last workgroups share the edge items (one item per thread when there are enough tiles; the
 // edge bodies are strided loops, so any count >= 1 covers all items)
@@ -181,6 +196,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
     hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     switch (variant) {
         case 0: CNT_ENC_STREAM(64, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
+#ifdef CNT_LAB_VARIANTS
         case 1: CNT_ENC_STREAM(256, 1, 1, kNT, kSC1); break;
         case 2: CNT_ENC_STREAM(512, 1, 1, kSC0 | kNT, kSC1); break;
         case 3: CNT_ENC_STREAM(256, 4, 1, kNT, kNT); break;
@@ -205,6 +221,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
         case 25: CNT_ENC_STREAM(64, 2, 1, kNT, kSC1); break;
         case 26: CNT_ENC_STREAM(128, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
         case 27: CNT_ENC_STREAM(64, 4, 1, kNT, kSC0 | kSC1 | kNT); break;
+#endif
         default: return 1;
     }
     }
@@ -255,10 +272,13 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
         const uint8_t* i0 = in + first * kRoundTripTile;
         uint8_t* p0 = packed + first * (kRoundTripTile / 4);
         uint8_t* b0 = back + first * kRoundTripTile;
-        if (shape == 1)
+#ifdef CNT_LAB_VARIANTS
+        if (shape == 1) {
             hipLaunchKernelGGL((round_trip_stream<64, 2, 2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(2 * n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)(2 * n_tiles), xs, e);
-        else
-            hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e);
+            continue;
+        }
+#endif
+        hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e);
     }
 }
 
@@ -285,6 +305,7 @@ void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2,
 // ---- decode -------------------------------------------------------------------------
 constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=64 U=4 xcd-quads ld=plain st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},  // 0: default (round 3; rounds 1-2: variant 35)
+#ifdef CNT_LAB_VARIANTS
     {"stream B=256 U=2 ld=plain st=sc0|sc1|nt", 256 * 2 * 16, 256, 0},        // 1
     {"stream B=64 U=2 xcd-pairs ld=plain st=sc0|sc1|nt", 64 * 2 * 16, 64, 0},  // 2
     {"stream B=256 U=2 ld=nt st=nt", 256 * 2 * 16, 256, 0},                   // 3: the first shape tried
@@ -339,6 +360,7 @@ constexpr VariantDesc kDecodeVariants[] = {
     {"stream B=64 U=8 xcd-pairs ld=plain st=sc0|sc1|nt, 7 wg/CU", 64 * 8 * 16, 64, 7},         // 43
     {"stream B=64 U=4 xcd-quads ld=sc1 st=sc0|sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},         // 44
     {"stream B=64 U=4 xcd-quads ld=plain st=sc1|nt, 14 wg/CU", 64 * 4 * 16, 64, 14},           // 45
+#endif
 };
 constexpr int kNumDecodeVariants = sizeof(kDecodeVariants) / sizeof(kDecodeVariants[0]);
 
@@ -365,6 +387,7 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     hipLaunchKernelGGL((bits_to_n_stream<B, U, C, L, S>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     switch (variant) {
         case 0: CNT_DEC_STREAM(64, 4, 4, 0, kAll); break;
+#ifdef CNT_LAB_VARIANTS
         case 1: CNT_DEC_STREAM(256, 2, 1, 0, kAll); break;
         case 2: CNT_DEC_STREAM(64, 2, 2, 0, kAll); break;
         case 3: CNT_DEC_STREAM(256, 2, 1, kNT, kNT); break;
@@ -400,6 +423,7 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
         case 45: CNT_DEC_STREAM(64, 4, 4, 0, kSC1 | kNT); break;
         case 36: case 37: CNT_DEC_STREAM(256, 2, 2, 0, kAll); break;
         case 21: CNT_DEC_STREAM(128, 2, 4, kNT, kAll); break;
+#endif
         default: return 1;
     }
     }

@@ -14,6 +14,7 @@ namespace cnt {
 // tile_nt = nucleotides per WAVE tile (WPL * 1728); a workgroup takes `waves` of them
 constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 0: default
+#ifdef CNT_LAB_VARIANTS
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=nt st=sc1", 4 * kWaveBytes5, 64, 0},   // 1
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},  // 2
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1", 2 * kWaveBytes5, 64, 0},  // 3
@@ -61,13 +62,22 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1, 5 wg/CU", 2 * kWaveBytes5, 64, 5},  // 40
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1, 7 wg/CU", 2 * kWaveBytes5, 64, 7},  // 41
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1, 8 wg/CU", 2 * kWaveBytes5, 64, 8},  // 42
+#endif
 };
+#ifdef CNT_LAB_VARIANTS
 inline int encode2_waves(int variant) { return variant == 3 || (variant >= 38 && variant <= 40) ? 4 : variant == 2 || variant == 41 || variant == 42 ? 2 : 1; }
 inline int encode2_pipe_k(int variant) { return variant == 28 || variant == 29 || variant == 30 || variant == 36 ? 2 : variant == 34 || variant == 35 ? 8 : (variant >= 31 && variant <= 37) ? 4 : 0; }
+#else
+constexpr int encode2_waves(int) { return 1; }
+constexpr int encode2_pipe_k(int) { return 0; }
+constexpr int decode2_waves(int) { return 1; }
+constexpr int decode2_pipe_k(int) { return 0; }
+#endif
 constexpr int kNumEncode2Variants = sizeof(kEncode2Variants) / sizeof(kEncode2Variants[0]);
 
 constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 0: default
+#ifdef CNT_LAB_VARIANTS
     {"wave-tiled 4 words/lane, 1 wave/wg, ld=plain st=sc0|sc1|nt", 4 * kWaveBytes5, 64, 0},   // 1
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 2
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt", 2 * kWaveBytes5, 64, 0},  // 3
@@ -115,9 +125,12 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt, 5 wg/CU", 2 * kWaveBytes5, 64, 5},  // 43
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt, 7 wg/CU", 2 * kWaveBytes5, 64, 7},  // 44
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt, 8 wg/CU", 2 * kWaveBytes5, 64, 8},  // 45
+#endif
 };
+#ifdef CNT_LAB_VARIANTS
 inline int decode2_waves(int variant) { return variant == 3 || (variant >= 41 && variant <= 43) ? 4 : variant == 2 || variant == 44 || variant == 45 ? 2 : 1; }
 inline int decode2_pipe_k(int variant) { return variant == 32 || variant == 33 || variant == 39 ? 2 : variant == 37 || variant == 38 ? 8 : (variant >= 34 && variant <= 40) ? 4 : 0; }
+#endif
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
 // Whole wave tiles of [d_n, d_n + n_len) plus -- for the one-wave variants, in the same (last) launch -- the edge words `e`
@@ -147,6 +160,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
     hipLaunchKernelGGL((n_to_bits2_wave<W, P, L, S, STRICT>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
 #define CNT_ENC2P(K, L, S) \
     hipLaunchKernelGGL((n_to_bits2_pipe<K, L, S, STRICT>), dim3(grid_of(n / K)), dim3(64), lds, s, in, out, e)
+#ifdef CNT_LAB_VARIANTS
         if (pk) {
             e.groups = first + n == total ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n / pk) : 0u;
             const uint32_t lds = lds_pad_for_cap(kEncode2Variants[variant].wg_cap, 4608u);  // the pipelined slab is a full 4 KiB (+16 B)
@@ -156,8 +170,10 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
             else CNT_ENC2P(8, kNT, kSC1);
             continue;
         }
+#endif
         switch (variant) {
             case 0: CNT_ENC2(1, 2, kNT, kSC1); break;
+#ifdef CNT_LAB_VARIANTS
             case 1: CNT_ENC2(1, 4, kNT, kSC1); break;
             case 2: case 41: case 42: CNT_ENC2(2, 2, kNT, kSC1); break;
             case 3: case 38: case 39: case 40: CNT_ENC2(4, 2, kNT, kSC1); break;
@@ -173,6 +189,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
             case 26: CNT_ENC2(1, 2, 0, kSC1); break;
             case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+#endif
             default: return 1;
         }
 #undef CNT_ENC2
@@ -222,6 +239,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
     hipLaunchKernelGGL((bits_to_n2_wave<W, P, L, S>), dim3(grid_of((n + W - 1) / W)), dim3(W * 64), lds, s, in, out, n, xs, e)
 #define CNT_DEC2P(K) \
     hipLaunchKernelGGL((bits_to_n2_pipe<K, 0, kAll>), dim3(grid_of(n / K)), dim3(64), lds, s, in, out, e)
+#ifdef CNT_LAB_VARIANTS
         if (pk) {
             e.groups = first + n == total ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n / pk) : 0u;
             const uint32_t lds = lds_pad_for_cap(kDecode2Variants[variant].wg_cap, 4608u);
@@ -230,8 +248,11 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             else CNT_DEC2P(8);
             continue;
         }
+#endif
         switch (variant) {
-            case 0: case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 0: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+#ifdef CNT_LAB_VARIANTS
+            case 20: case 21: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 19: case 11: case 12: case 16: case 17: case 18: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 1: CNT_DEC2(1, 4, 0, kAll); break;
             case 2: case 44: case 45: CNT_DEC2(2, 2, 0, kAll); break;
@@ -246,6 +267,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 29: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kSC1 | kNT, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 30: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 31: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kSC1, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+#endif
             default: return 1;
         }
 #undef CNT_DEC2

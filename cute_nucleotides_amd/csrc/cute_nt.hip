@@ -6,9 +6,8 @@
 //   sharded tier        contiguous chunks over the visible devices, one host
 //                       thread per device, no collective;
 //   device-pointer tier enqueue-only; what the roofline numbers measure.
-// No global mutable state apart from the tuning knobs (atomics); streams and
-// scratch are per calling thread, so the library is re-entrant like the
-// reference's pure functions.
+// No global mutable state that selects code (the tuning knobs exist in the lab build only, see below); streams and
+// scratch are per calling thread, so the library is re-entrant like the reference's pure functions.
 //
 // One translation unit (the kernel headers define non-template __global__ functions), split for reading:
 //   shim_host_ctx.inc   staging-copy pool, per-thread / per-device context, huge-page advice
@@ -61,7 +60,13 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? CNT_OK : -(int)e; }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// ---- tuning knobs -------------------------------------------------------------
+// ---- tuning knobs: LAB BUILD ONLY -------------------------------------------------------
+// The product library selects nothing at run time: every tune_*() below is a compile-time constant there, the variant
+// tables hold their default entry only, and cnt_set_tuning() answers CNT_EINVAL for every key -- no thread can change the
+// kernel under another thread's call (the header's re-entrancy contract; the reference's functions are pure over
+// immutable tables, n_to_bits.rs:8,23).  -DCNT_LAB_VARIANTS (bench/libcute_nt_hip_lab.so) turns them into process-global
+// atomics for A/B runs and for the tests that walk variants, tile maps and the several-launch loops.
+#ifdef CNT_LAB_VARIANTS
 // Index into kEncodeVariants / kDecodeVariants (codec2_launch.hpp); 0 = shipped default.
 std::atomic<int> g_encode_variant{0};
 std::atomic<int> g_decode_variant{0};
@@ -75,6 +80,22 @@ std::atomic<int> g_reduce_persistent{1};  // 1 = hamming / validate as one launc
 std::atomic<int> g_reduce_fallbacks{0};  // hamming / validate calls that could not get their stream-ordered scratch and ran the generic kernel
 std::atomic<int> g_round_trip_shape{0};  // 0 = <64, 4, 1> (default), 1 = <64, 2, 2> (the first shipped shape), codec2_launch.hpp
 std::atomic<int> g_round_trip_cap{(int)kRoundTripDefaultCap};  // resident one-wave workgroups per CU of the fused round-trip kernel
+inline int tune_encode() { return g_encode_variant.load(std::memory_order_relaxed); }
+inline int tune_decode() { return g_decode_variant.load(std::memory_order_relaxed); }
+inline int tune_encode2() { return g_encode2_variant.load(std::memory_order_relaxed); }
+inline int tune_decode2() { return g_decode2_variant.load(std::memory_order_relaxed); }
+inline size_t tune_small_nt() { return (size_t)g_small_nt.load(std::memory_order_relaxed); }
+inline int tune_round_trip_shape() { return g_round_trip_shape.load(std::memory_order_relaxed); }
+inline uint32_t tune_round_trip_cap() { return (uint32_t)g_round_trip_cap.load(std::memory_order_relaxed); }
+#else
+constexpr int tune_encode() { return 0; }
+constexpr int tune_decode() { return 0; }
+constexpr int tune_encode2() { return 0; }
+constexpr int tune_decode2() { return 0; }
+constexpr size_t tune_small_nt() { return (size_t)1 << 17; }
+constexpr int tune_round_trip_shape() { return 0; }
+constexpr uint32_t tune_round_trip_cap() { return kRoundTripDefaultCap; }
+#endif
 
 inline unsigned generic_grid(uint64_t items) {
     uint64_t b = (items + kBlock - 1) / kBlock;
@@ -378,6 +399,7 @@ int cnt_count_mismatch_dev(const void* d_a, const void* d_b, size_t nbytes, void
 // ---- tuning -------------------------------------------------------------------------
 int cnt_set_tuning(const char* key, int value) {
     if (!key) return CNT_EINVAL;
+#ifdef CNT_LAB_VARIANTS
     if (!strcmp(key, "encode")) {
         if (value < 0 || value >= kNumEncodeVariants) return CNT_EINVAL;
         g_encode_variant.store(value);
@@ -415,26 +437,42 @@ int cnt_set_tuning(const char* key, int value) {
         return CNT_EINVAL;
     }
     return CNT_OK;
+#else
+    (void)value;
+    return CNT_EINVAL;  // the product library has nothing to select: build bench/libcute_nt_hip_lab.so for A/B runs
+#endif
 }
 
 int cnt_get_tuning(const char* key, int* value) {
     if (!key || !value) return CNT_EINVAL;
-    if (!strcmp(key, "encode")) *value = g_encode_variant.load();
-    else if (!strcmp(key, "decode")) *value = g_decode_variant.load();
-    else if (!strcmp(key, "encode2")) *value = g_encode2_variant.load();
-    else if (!strcmp(key, "decode2")) *value = g_decode2_variant.load();
-    else if (!strcmp(key, "small_nt")) *value = g_small_nt.load();
+    if (!strcmp(key, "lab_build")) {
+#ifdef CNT_LAB_VARIANTS
+        *value = 1;
+#else
+        *value = 0;
+#endif
+    } else if (!strcmp(key, "encode")) *value = tune_encode();
+    else if (!strcmp(key, "decode")) *value = tune_decode();
+    else if (!strcmp(key, "encode2")) *value = tune_encode2();
+    else if (!strcmp(key, "decode2")) *value = tune_decode2();
+    else if (!strcmp(key, "small_nt")) *value = (int)tune_small_nt();
     else if (!strcmp(key, "xcd_shift")) *value = (int)xcd_shift();
-    else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
-    else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
-    else if (!strcmp(key, "round_trip_cap")) *value = g_round_trip_cap.load();
-    else if (!strcmp(key, "round_trip_shape")) *value = g_round_trip_shape.load();
-    else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
-    else if (!strcmp(key, "reduce_persistent")) *value = g_reduce_persistent.load();
+    else if (!strcmp(key, "round_trip_cap")) *value = (int)tune_round_trip_cap();
+    else if (!strcmp(key, "round_trip_shape")) *value = tune_round_trip_shape();
     else if (!strcmp(key, "encode_variants")) *value = kNumEncodeVariants;
     else if (!strcmp(key, "decode_variants")) *value = kNumDecodeVariants;
     else if (!strcmp(key, "encode2_variants")) *value = kNumEncode2Variants;
     else if (!strcmp(key, "decode2_variants")) *value = kNumDecode2Variants;
+#ifdef CNT_LAB_VARIANTS
+    else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
+    else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
+    else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
+    else if (!strcmp(key, "reduce_persistent")) *value = g_reduce_persistent.load();
+#else
+    else if (!strcmp(key, "launch_tiles")) *value = 0;
+    else if (!strcmp(key, "reduce_persistent")) *value = 1;
+    else if (!strcmp(key, "reduce_fallbacks")) *value = 0;  // the form that could fall back is not in the product
+#endif
     else return CNT_EINVAL;
     return CNT_OK;
 }

@@ -40,7 +40,15 @@ def count_mismatch(a, b):
 
 
 def set_tuning(key, value):
-    check(lib().cnt_set_tuning(key.encode(), int(value)))
+    """LAB BUILD ONLY (cute_nucleotides_amd._lib.use_lab_build()): the product library has nothing to select and answers
+    CNT_EINVAL for every key."""
+    from . import _lib
+
+    rc = lib().cnt_set_tuning(key.encode(), int(value))
+    if rc == _lib.CNT_EINVAL and not _lib.is_lab_build():
+        raise _lib.CuteNtError(rc, "cnt_set_tuning(%r): the product library has no run-time kernel selection; call "
+                                   "cute_nucleotides_amd._lib.use_lab_build() first (bench/libcute_nt_hip_lab.so)" % key)
+    check(rc)
 
 
 def get_tuning(key):

@@ -226,9 +226,9 @@ int cnt_dev_sync(void *stream);
  * that the caller zeroes (the call adds to them).  Like the codec entry points these neither
  * synchronise nor allocate (capturable in a HIP graph): the two reductions (hamming, validate)
  * are ONE launch of persistent waves that end in one atomic each.  (Round 1's form -- tiles, a
- * stream-ordered scratch array from hipMallocAsync, a second kernel -- stays selectable with
- * cnt_set_tuning("reduce_persistent", 0) for A/B runs; only that form allocates, and
- * cnt_get_tuning("reduce_fallbacks") counts the calls in which its allocation failed.)
+ * stream-ordered scratch array from hipMallocAsync, a second kernel -- exists in the lab build only,
+ * cnt_set_tuning("reduce_persistent", 0); only that form allocates, and cnt_get_tuning("reduce_fallbacks")
+ * counts the calls in which its allocation failed.)
  * Host tier: synchronous.
  *   hamming             #{ i < len : code_a(i) != code_b(i) }
  *   complement          A<->T, C<->G
@@ -255,21 +255,24 @@ int cnt_checksum_words_dev(const void *d_words, size_t first_word, size_t words,
 /* *d_count (device u64, caller zeroes it) += number of differing bytes. */
 int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void *d_count, void *stream);
 
-/* Kernel-variant override for tuning / A-B runs (bench/ only; variant 0 is the shipped,
- * measured-best default).  key "encode" / "decode" (2-bit codec), "encode2" / "decode2"
- * (5-letter codec): value = variant index; cnt_get_tuning also answers "<key>_variants"
- * (the counts).  key "small_nt": inputs of at most this many nucleotides that are not a whole
- * number of tiles take ONE generic-kernel launch instead of tiles + ragged end (default 2^17,
- * 0 = never); "round_trip_cap": resident workgroups per CU of the fused kernel, "round_trip_shape": 0 (default: one
- * wave x four loads, plain order) / 1 (the first shipped shape: two loads, XCD pairs; pair it with cap 13); "reduce_persistent":
- * 1 (default) = hamming / validate as one launch of persistent waves, 0 = round 1's tiles + scratch + second pass, whose
- * tiles read their pages XCD-interleaved when "reduce_xi" is 1.
- * "xcd_shift": log2 of the XCD count the block -> tile maps assume (-1 = ask the device, the default; get returns the
- * value in effect) -- the maps are bijections for every value, only speed depends on it.
- * "launch_tiles": most tiles one kernel launch may take (a multiple of 64; 0 = the hardware's limit of 2^31-1 threads,
- * the default) -- test support: lets a few MiB walk the several-launch loops that otherwise start at 2^36 nt.
- * cnt_tuning_name returns the variant's description (NULL when out of range).
- * CNT_EINVAL for unknown keys / values. */
+/* Kernel selection for A/B runs: LAB BUILD ONLY.  The product library (libcute_nt_hip.so) holds the shipped default of every
+ * kernel family plus the any-alignment kernels and has NO run-time selection of code: cnt_set_tuning answers CNT_EINVAL for
+ * every key, the getters answer constants ("encode" = 0, "encode_variants" = 1, "small_nt" = 2^17, "lab_build" = 0, ...) --
+ * like the reference's functions over immutable tables (n_to_bits.rs:8,23), nothing one thread does can change the kernel
+ * under another thread's call.  The same sources built with -DCNT_LAB_VARIANTS (bench/libcute_nt_hip_lab.so,
+ * cute_nucleotides_amd/build.py build_lab) add every measured variant and these process-global knobs:
+ *   "encode" / "decode" (2-bit codec), "encode2" / "decode2" (5-letter codec): variant index, 0 = the shipped default;
+ *   cnt_get_tuning also answers "<key>_variants" (the counts).  "small_nt": inputs of at most this many nucleotides that
+ *   are not a whole number of tiles take ONE generic-kernel launch instead of tiles + edge workgroups (default 2^17, 0 =
+ *   never); "round_trip_cap": resident workgroups per CU of the fused kernel, "round_trip_shape": 0 (default: one wave x
+ *   four loads, plain order) / 1 (the first shipped shape: two loads, XCD pairs; pair it with cap 13); "reduce_persistent":
+ *   1 (default) = hamming / validate as one launch of persistent waves, 0 = round 1's tiles + scratch + second pass, whose
+ *   tiles read their pages XCD-interleaved when "reduce_xi" is 1.  "xcd_shift": log2 of the XCD count the block -> tile
+ *   maps assume (-1 = ask the device, the default; get returns the value in effect) -- the maps are bijections for every
+ *   value, only speed depends on it.  "launch_tiles": most tiles one kernel launch may take (a multiple of 64; 0 = the
+ *   hardware's limit of 2^31-1 threads, the default) -- test support: lets a few MiB walk the several-launch loops that
+ *   otherwise start at 2^36 nt.
+ * cnt_tuning_name returns the variant's description (NULL when out of range).  CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);
 int cnt_get_tuning(const char *key, int *value);
 const char *cnt_tuning_name(const char *key, int value);

@@ -27,6 +27,20 @@ def oracle():
     return cnt_oracle
 
 
+@pytest.fixture()
+def lab_build():
+    """Run this test against bench/libcute_nt_hip_lab.so (-DCNT_LAB_VARIANTS: every kernel variant + cnt_set_tuning) instead of
+    the product library, which has no run-time kernel selection.  Parity tests that need no knob run on the product build;
+    the variant sweeps, the tile-map / several-launch-loop tests and everything that forces a path through a tuning key
+    take this fixture (directly or through `tuning` / `no_small_path` / `launch_tiles` / `reduce_form`)."""
+    from cute_nucleotides_amd import _lib
+
+    prev = _lib.use_lab_build(True)
+    assert _lib.lib().cnt_set_tuning(b"small_nt", 1 << 17) == 0  # really the lab build
+    yield
+    _lib.use_lab_build(prev)
+
+
 @pytest.fixture(scope="session")
 def kats():
     import json

@@ -94,9 +94,27 @@ def test_argument_errors_before_any_device_work(L):
     assert L.cnt_fill_random_acgtn_dev(p(buf), 5, 27, 1, None) == _lib.CNT_ERANGE
 
 
-def test_tuning_knobs(L):
-    from cute_nucleotides_amd import devutil
+def test_product_build_has_no_kernel_selection(L):
+    """the product library contains the default kernels only and nothing that selects code at
+    run time -- every cnt_set_tuning key is CNT_EINVAL, the variant tables hold one entry, the getters answer constants."""
+    from cute_nucleotides_amd import _lib, devutil
 
+    assert not _lib.is_lab_build() and devutil.get_tuning("lab_build") == 0
+    for key in ("encode", "decode", "encode2", "decode2", "round_trip_shape", "round_trip_cap", "reduce_persistent", "reduce_xi",
+                "xcd_shift", "small_nt", "launch_tiles", "nonsense"):
+        assert L.cnt_set_tuning(key.encode(), 0) == _lib.CNT_EINVAL, key
+    for key in ("encode", "decode", "encode2", "decode2"):
+        assert devutil.get_tuning(key) == 0 and devutil.get_tuning(key + "_variants") == 1
+        assert L.cnt_tuning_name(key.encode(), 0) and L.cnt_tuning_name(key.encode(), 1) is None
+    assert devutil.get_tuning("small_nt") == 1 << 17 and devutil.get_tuning("reduce_persistent") == 1
+    with pytest.raises(_lib.CuteNtError, match="use_lab_build"):
+        devutil.set_tuning("encode", 0)
+
+
+def test_tuning_knobs(L, lab_build):
+    from cute_nucleotides_amd import _lib, devutil
+
+    L = _lib.lib()  # the lab build
     for key in ("encode", "decode"):
         old = devutil.get_tuning(key)
         assert old == 0  # the shipped default

@@ -36,7 +36,7 @@ def cn():
 
 
 @pytest.fixture()
-def tuning():
+def tuning(lab_build):
     from cute_nucleotides_amd import devutil
 
     saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "small_nt")}
@@ -437,6 +437,42 @@ def test_decode_alignment_matrix(cn, oracle, torch_cuda, tuning):
 
 
 
+def test_alignment_matrix_on_the_product_build(cn, oracle, torch_cuda):
+    """The two matrices above force the tile kernels onto small inputs through a lab-build knob.  The product library has
+    no knob: here the same head peel / window / funnel-shift paths run as shipped, at sizes past its small-input path
+    (2^17 nt), a reduced matrix of input byte phase x packed-word phase x output byte phase, guards around every output."""
+    from cute_nucleotides_amd import _lib
+
+    assert not _lib.is_lab_build()
+    torch = torch_cuda
+    sizes = [(1 << 17) + 2048 * 3 + 149, (1 << 17) + 4096 + 129, (1 << 18) + 100003]
+    big = _rand_valid(max(sizes), 79)
+    ibuf = torch.zeros(big.size + 256, dtype=torch.uint8, device="cuda")
+    pbuf = torch.empty(big.size // 32 + 64, dtype=torch.int64, device="cuda")
+    obuf = torch.empty(big.size + 512, dtype=torch.uint8, device="cuda")
+    for n_len in sizes:
+        n = big[:n_len]
+        want = oracle.n_to_bits_lut(n)
+        want_back = oracle.bits_to_n_lut(want, n_len)
+        words = want.size
+        for io in (0, 1, 5, 16, 17, 63, 64, 100, 127):
+            view = ibuf[io : io + n_len]
+            view.copy_(torch.from_numpy(n))
+            for po in (0, 1, 7, 8, 15):
+                pbuf.fill_(-1)
+                out = pbuf[8 + po : 8 + po + words]
+                cn.n_to_bits_dev(view, out=out)
+                got = pbuf.cpu().numpy()
+                assert (got[: 8 + po] == -1).all() and (got[8 + po + words :] == -1).all(), (n_len, io, po)
+                assert np.array_equal(got[8 + po : 8 + po + words].view(np.uint64), want), (n_len, io, po)
+                for oo in (0, 1, 15, 16, 33, 64, 127) if io in (0, 5) else (3,):
+                    obuf.fill_(0x2A)
+                    cn.bits_to_n_dev(out, n_len, out=obuf[128 + oo : 128 + oo + n_len])
+                    b = obuf.cpu().numpy()
+                    assert (b[: 128 + oo] == 0x2A).all() and (b[128 + oo + n_len :] == 0x2A).all(), (n_len, po, oo)
+                    assert np.array_equal(b[128 + oo : 128 + oo + n_len], want_back), (n_len, po, oo)
+
+
 def test_decode_large_buffer_4k_head(cn, oracle, torch_cuda):
     """>= 2^20 nt: the head is peeled up to a 4-KiB boundary of the output (range kernel), then the
     funnel-shifting tiles, then a ragged end that does not start on a word."""
@@ -805,13 +841,12 @@ def _kernel_nodes_of(torch, fn):
     return n.value
 
 
-def test_any_size_and_alignment_is_one_launch(cn, oracle, torch_cuda, tuning):
+def test_any_size_and_alignment_is_one_launch(cn, oracle, torch_cuda):
     """VERDICT r02 item 3: encode_dev / decode_dev used to enqueue up to three kernels (head peel, tiles, ragged end);
     each extra launch cost ~5 us behind a 0.2 ms kernel at BASELINE.json's 1 GiB size.  The head words and the ragged
     end are now extra workgroups of the tile kernel's own grid: ONE node in a captured graph for every size and
     pointer phase -- and the results are still the oracle's."""
-    torch = torch_cuda
-    tuning.set_tuning("small_nt", 0)
+    torch = torch_cuda  # the PRODUCT build as shipped: 2^21 - 19 nt is past the small-input path (2^17)
     n_len = (1 << 21) - 19
     host = _rand_valid(n_len, 4)
     want = oracle.n_to_bits_lut(host)
@@ -899,7 +934,7 @@ def test_config4_rank_shard_at_its_global_offset(cn, oracle, torch_cuda, fullsiz
 
 
 @pytest.mark.parametrize("xs", [0, 1, 2, 3, 4, 5])
-def test_tile_maps_are_bijections_for_any_xcd_count(cn, oracle, torch_cuda, xs):
+def test_tile_maps_are_bijections_for_any_xcd_count(cn, oracle, torch_cuda, lab_build, xs):
     """the XCD count is asked of the device and reaches the kernels as log2 X.  Partition modes
     (CPX / DPX / QPX: 1 / 2 / 4 XCDs per device) cannot be switched on here, so the tuning key "xcd_shift" walks every
     value a device could answer (and two it could not): the block -> tile maps of every kernel family -- encode pairs,

@@ -11,7 +11,7 @@ SIZES = [1, 2, 3, 4, 5, 26, 27, 28, 53, 54, 55, 80, 81, 82, 6911, 6912, 6913, 69
 
 
 @pytest.fixture()
-def no_small_path():
+def no_small_path(lab_build):
     """small ragged inputs normally take the generic kernel alone: switch that off to reach the tiles"""
     from cute_nucleotides_amd import devutil
 
@@ -42,13 +42,15 @@ def test_encode_decode_host_tier(cn, oracle, n_len):
     assert bytes(back) == bytes(n).upper().replace(b"U", b"T")
 
 
-@pytest.mark.parametrize("small_nt", [0, 1 << 17])
-def test_device_tier_aligned_unaligned_and_overrun(cn, oracle, small_nt):
+@pytest.mark.parametrize("small_nt", [0, 1 << 17], ids=["lab: tiles at every size", "product build"])
+def test_device_tier_aligned_unaligned_and_overrun(cn, oracle, request, small_nt):
     import torch
 
     from cute_nucleotides_amd import devutil
 
-    devutil.set_tuning("small_nt", small_nt)
+    if small_nt == 0:  # forcing the tile path for small inputs needs the lab build's knob; the other case is the product as shipped
+        request.getfixturevalue("lab_build")
+        devutil.set_tuning("small_nt", 0)
     n_len = 6912 * 5 + 100
     n = oracle.fill_random_acgtn(n_len, 5)
     want = oracle.n_to_bits2_lut(n)
@@ -71,7 +73,8 @@ def test_device_tier_aligned_unaligned_and_overrun(cn, oracle, small_nt):
             assert np.array_equal(got[off : off + length], oracle.bits_to_n2_lut(want, length)), (length, off)
     with pytest.raises(ValueError, match="The length is greater than the number of nucleotides!"):
         cn.bits_to_n2_dev(dbits, want.size * 27 + 1)
-    devutil.set_tuning("small_nt", 1 << 17)
+    if small_nt == 0:
+        devutil.set_tuning("small_nt", 1 << 17)
 
 
 @pytest.mark.parametrize("strict", [False, True])
@@ -177,7 +180,7 @@ def test_large_round_trip(cn, oracle):
 
 
 @pytest.mark.parametrize("key", ["encode2", "decode2"])
-def test_every_variant(cn, oracle, key):
+def test_every_variant(cn, oracle, lab_build, key):
     import torch
 
     from cute_nucleotides_amd import devutil
@@ -275,7 +278,7 @@ TAIL_SIZES5 = [1, 4, 5, 6, 26, 27, 28, 31, 32, 33, 53, 54, 58, 59, 60, 81, 3456,
                100003, 27 * 40000, 27 * 40000 + 5, (1 << 20) + 11, 27 * (1 << 19) + 13824 * 2, 27 * (1 << 19) + 13824 * 2 + 4]
 
 
-def test_tail_lut_equals_n_to_bits2_pext_on_arbitrary_bytes(cn, oracle):
+def test_tail_lut_equals_n_to_bits2_pext_on_arbitrary_bytes(cn, oracle, lab_build):
     """n_to_bits2_pext runs its low-3-bit table over words [0, (len-5)/27) -- its 32-byte loads would over-read 5 bytes
     beyond that -- and hands every later word (one or two, whole or ragged) to n_to_bits2_lut (n_to_bits2.rs:120,179-185).
     On foreign bytes the two tables differ ('B' = 0x42 has low bits 010 -> 0 in both, but 'D' = 0x44 -> T in the fast

@@ -26,12 +26,17 @@ def _lengths(rng, k):
 
 @pytest.fixture(params=[0, 1 << 17], ids=["tiles", "small-path"])
 def small_nt(request):
-    """with and without the single-launch path for small ragged inputs (tuning key small_nt)"""
+    """with the single-launch path for small ragged inputs (the product build as shipped) and without it (lab build,
+    tuning key small_nt = 0: the tile kernels and their edge workgroups at every size)"""
+    if request.param:
+        yield request.param
+        return
+    request.getfixturevalue("lab_build")
     from cute_nucleotides_amd import devutil
 
     saved = devutil.get_tuning("small_nt")
-    devutil.set_tuning("small_nt", request.param)
-    yield request.param
+    devutil.set_tuning("small_nt", 0)
+    yield 0
     devutil.set_tuning("small_nt", saved)
 
 

@@ -17,7 +17,7 @@ ALPHA5 = np.frombuffer(b"ACGTNacgtnUu", dtype=np.uint8)
 
 
 @pytest.fixture(params=[64, 128])
-def launch_tiles(request):
+def launch_tiles(request, lab_build):
     from cute_nucleotides_amd import devutil
 
     saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "encode2", "decode2", "small_nt", "reduce_persistent")}
@@ -30,7 +30,7 @@ def launch_tiles(request):
         devutil.set_tuning(k, v)
 
 
-def test_launch_tiles_key_is_validated():
+def test_launch_tiles_key_is_validated(lab_build):
     from cute_nucleotides_amd import devutil
 
     for bad in (-64, 1, 63, 100):

@@ -3,7 +3,8 @@ disassembly -- streaming `nt` loads, write-through `sc0 sc1 nt` stores, `v_perm_
 in the 5-letter packer, no waterfall loops, no scratch, register counts far below the residency caps -- and nothing
 checked it: a compiler bump could reintroduce a waterfall loop and only show up as a few percent on the GPU box.
 hipcc cross-compiles gfx950 without a GPU, so the assembly of the library's one translation unit is regenerated here
-(~5 s), compared with the committed digest (profiles/r03_isa_digest.txt) and checked property by property."""
+(~5 s), compared with the committed digest (profiles/r04_isa_digest.txt) and checked property by property.  Round 4 also
+checks what the PRODUCT code object contains: the default kernels and the any-alignment kernels, none of the lab's."""
 import os
 import sys
 
@@ -32,6 +33,31 @@ def test_committed_digest_is_current(isa):
     got = isa_digest.digest(found)
     assert "MISSING" not in got
     assert got == want, "the compiler's output changed: review the diff, then `python bench/isa_digest.py --write`"
+
+
+def test_defaults_have_not_moved_since_round_3(isa):
+    """splitting the lab variants out of the product must not touch the shipped kernels -- every block of
+    round 3's committed digest is, line for line, a block of round 4's."""
+    isa_digest, _ = isa
+    now = open(isa_digest.DIGEST).read()
+    old = open(isa_digest.DIGEST_R03).read()
+    blocks = [b for b in ("\n" + old).split("\n") if b]
+    for line in blocks:
+        assert line in now.split("\n"), "round 3's digest line is gone from round 4's: " + line
+
+
+def test_product_code_object_holds_no_lab_kernels(isa):
+    """the product library = defaults + the any-alignment kernels + generic / staged / utility kernels; every measured
+    alternative (LDS-widened, pipelined, multi-wave, round 1's reductions, other shapes and policies) is lab-only"""
+    isa_digest, found = isa
+    names = sorted(found)
+    for needle in ("n_to_bits_lds", "bits_to_n_lds", "n_to_bits2_pipe", "bits_to_n2_pipe", "hamming_tiles", "validate_tiles", "sum_partials"):
+        assert not [n for n in names if needle in n], (needle, [n for n in names if needle in n])
+    assert len([n for n in names if "cnt::n_to_bits_stream<" in n]) == 2  # default, strict and default
+    assert len([n for n in names if "cnt::bits_to_n_stream<" in n]) == 1
+    assert len([n for n in names if "cnt::n_to_bits2_wave<" in n]) == 2 and len([n for n in names if "cnt::bits_to_n2_wave<" in n]) == 1
+    assert len([n for n in names if "cnt::round_trip_stream<" in n]) == 2 and len([n for n in names if "cnt::round_trip_window<" in n]) == 2
+    assert len(names) < 60, len(names)
 
 
 def test_every_shipped_kernel_is_lean(isa):
@@ -66,6 +92,12 @@ def test_2bit_codec_instruction_selection(isa):
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
     assert t["counts"]["buffer_load_dwordx4"] == 4 and t["counts"]["buffer_store_dword"] == 4 and t["counts"]["buffer_store_dwordx4"] == 4
     assert "s_and_saveexec_b64" not in t["counts"]
+    # the any-alignment twin: five window loads (the fifth reaches past the descriptor for most lanes: no branch), two funnel
+    # reads per output pair, the same stores
+    t, w, m = _tile(isa_digest, found, "void cnt::round_trip_window<1, 2, 19, false>")
+    assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
+    assert t["counts"]["buffer_load_dwordx4"] == 5 and t["counts"]["buffer_store_dword"] == 4 and t["counts"]["buffer_store_dwordx4"] == 4
+    assert t["counts"]["v_alignbit_b32"] == 8 and "s_and_saveexec_b64" not in t["counts"] and m["next_free_vgpr"] <= 64
 
 
 def test_5letter_codec_instruction_selection(isa):

@@ -53,12 +53,16 @@ SIZES = [0, 1, 5, 31, 32, 33, 63, 64, 65, 1000, 4099, 32 * 8192, 32 * 8192 + 7, 
 
 @pytest.fixture(params=[1, 0], ids=["persistent", "tiles+second-pass"])
 def reduce_form(request):
-    """both forms of the reductions: one launch of persistent waves (shipped) and round 1's tiles + stream-ordered
-    scratch + second pass (selectable for A/B runs: tuning key reduce_persistent)"""
+    """both forms of the reductions: one launch of persistent waves (shipped: the product build, no knob) and round 1's
+    tiles + stream-ordered scratch + second pass (lab build only, tuning key reduce_persistent)"""
+    if request.param == 1:
+        yield 1
+        return
+    request.getfixturevalue("lab_build")
     from cute_nucleotides_amd import devutil
 
-    devutil.set_tuning("reduce_persistent", request.param)
-    yield request.param
+    devutil.set_tuning("reduce_persistent", 0)
+    yield 0
     devutil.set_tuning("reduce_persistent", 1)
 
 
