@@ -71,6 +71,25 @@ def traffic_summary(fetch_csv, write_csv, n, tag=""):
     return summary
 
 
+def stats_by_grid(trace_csv, out_csv):
+    """rocprofv3's --stats table groups by kernel NAME only: a call that a launcher cuts into a big and a tiny launch, or a
+    workload that runs the same kernel at two sizes, gets one meaningless average (round 3's fused 2^36 file: 4-us and
+    22.8-ms launches of one kernel averaged to 11.4 ms).  This writes the same columns from the per-dispatch kernel trace
+    grouped by (kernel, grid size), largest total first."""
+    import statistics
+
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace_csv)):
+        groups[(r["Kernel_Name"], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in groups.values()) or 1
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "GridThreads", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for (name, grid), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, grid, len(v), sum(v), round(sum(v) / len(v), 3), round(100.0 * sum(v) / total, 3), min(v), max(v),
+                        round(statistics.pstdev(v), 3)])
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     log2_nt = int(sys.argv[2]) if len(sys.argv) > 2 else 34
@@ -80,8 +99,8 @@ def main():
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
     f36 = os.path.join(src, "stats_fused36", "fused36_kernel_stats.csv")
-    if os.path.exists(f36):  # rocprofv3 --stats of a 2^36-nt fused round trip (BASELINE.json configs[3])
-        shutil.copy(f36, os.path.join(dst, tag + "_fused_2p36_kernel_stats.csv"))
+    if os.path.exists(f36):  # rocprofv3 --kernel-trace of a 2^36-nt fused round trip (BASELINE.json configs[3]), one row per (kernel, grid)
+        stats_by_grid(os.path.join(src, "stats_fused36", "fused36_kernel_trace.csv"), os.path.join(dst, tag + "_fused_2p36_kernel_stats.csv"))
         shutil.copy(os.path.join(src, "fused36_under_rocprof.jsonl"), os.path.join(dst, tag + "_fused_2p36_under_rocprof.jsonl"))
     n = 1 << log2_nt
     summary = traffic_summary(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"),
