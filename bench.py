@@ -55,7 +55,8 @@ for _p in (ROOT, os.path.join(ROOT, "bench")):
 # timing loops and the extra blocks of the N = 1 line; bench_single_process.py = `--gpus N` without a launcher.  This file
 # keeps the arguments, the CPU-baseline leg (the only code allowed to touch oracle/), the timed region and the JSON line.
 from bench_measure import (BYTES_PER_NT, HBM_PEAK_GBS, HOST_TIER_LOG2, crossover, gbs, gpu_numa_node, host_placement,  # noqa: E402,F401
-                           load_probes, measure_ceilings, measure_codec5, measure_host_tier, measure_packed_ops, measure_pcie,
+                           load_probes, measure_ceilings, measure_codec5, measure_config3_64gib, measure_configs_1gib, measure_host_tier,
+                           measure_packed_ops, measure_pcie,
                            measure_traffic_live, numpy_pack, physical_cores, sockets, stats_ms, timed_calls, timed_queued)
 
 def parse_args():
@@ -382,41 +383,8 @@ def main():
             fused["verified"] = devutil.count_mismatch(d_in, d_out) == 0 and devutil.checksum_words(d_packed) == packed_sum
             verified = verified and fused["verified"]
 
-    # ---- BASELINE.json configs[1] / [2]: 1 GiB, on the first 2^30 nt of the same buffers ---------------------
-    configs = {}
-    if extras and n_len >= (1 << 30):
-        m = 1 << 30
-        enc30 = lambda: cn.n_to_bits_dev(d_in[:m], out=d_packed[: m // 32])
-        dec30 = lambda: cn.bits_to_n_dev(d_packed[: m // 32], m, out=d_out[:m])
-        # average launch duration with 10 launches queued per event pair (what the headline's timed region and rocprofv3
-        # see); the isolated single-launch figure, which also counts the host's event-to-launch gap, is kept beside it
-        e30, d30 = timed_queued(torch, enc30, 8, 10, warm=2), timed_queued(torch, dec30, 8, 10, warm=2)
-        e30s, d30s = timed_calls(torch, enc30, 10, warm=1), timed_calls(torch, dec30, 10, warm=1)
-        for key, lst, single in (("configs[1] n_to_bits encode, 1 GiB (2^30 nt)", e30, e30s), ("configs[2] bits_to_n decode, 1 GiB (2^30 nt)", d30, d30s)):
-            st = stats_ms(lst)
-            configs[key] = {"ms": st, "timing": "10 launches queued per HIP-event pair, 8 pairs", "gnts": round(m / (st["median"] * 1e-3) / 1e9, 1),
-                            "achieved_GBs": round(gbs(BYTES_PER_NT * m, st["median"]), 1),
-                            "frac": round(gbs(BYTES_PER_NT * m, st["median"]) / HBM_PEAK_GBS, 4),
-                            "isolated_single_launch": {"ms": stats_ms(single), "frac": round(gbs(BYTES_PER_NT * m, statistics.median(single)) / HBM_PEAK_GBS, 4)}}
-        if verified is not None:
-            configs["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]["round_trip_verified"] = devutil.count_mismatch(d_in[:m], d_out[:m]) == 0
-        # a size that is not a multiple of 32 (tail kernels, zero-padded last word) in the same run
-        r = m - 19  # 2^30 - 19 = 32 * (2^25 - 1) + 13: thirteen nucleotides in the last word
-        if n_len >= r:
-            encr = lambda: cn.n_to_bits_dev(d_in[:r], out=d_packed[: r // 32 + 1])
-            decr = lambda: cn.bits_to_n_dev(d_packed[: r // 32 + 1], r, out=d_out[:r])
-            er, dr = timed_queued(torch, encr, 8, 10, warm=2), timed_queued(torch, decr, 8, 10, warm=2)
-            assert r % 32 == 13
-            row = {"encode_ms": stats_ms(er), "decode_ms": stats_ms(dr), "timing": "10 launches queued per HIP-event pair, 8 pairs",
-                   "launches_per_call": 1,  # head words and ragged end ride in the tile kernel's grid (tests/test_gpu_codec2.py counts the graph nodes)
-                   "encode_frac": round(gbs(BYTES_PER_NT * r, statistics.median(er)) / HBM_PEAK_GBS, 4),
-                   "decode_frac": round(gbs(BYTES_PER_NT * r, statistics.median(dr)) / HBM_PEAK_GBS, 4),
-                   "encode_vs_aligned_2p30": round(statistics.median(er) / statistics.median(e30), 4),
-                   "decode_vs_aligned_2p30": round(statistics.median(dr) / statistics.median(d30), 4)}
-            if verified is not None:
-                last = int(d_packed[r // 32].item()) & 0xFFFFFFFFFFFFFFFF
-                row["round_trip_verified"] = devutil.count_mismatch(d_in[:r], d_out[:r]) == 0 and (last >> 26) == 0  # 13 nt used, 38 high bits zero
-            configs["ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)"] = row
+    # ---- BASELINE.json configs[1] / [2]: 1 GiB, and a ragged size, on the first 2^30 nt of the same buffers (bench_measure.py) ----
+    configs = measure_configs_1gib(torch, d_in, d_packed, d_out, verified is not None) if extras and n_len >= (1 << 30) else {}
 
     # ---- same-run, same-box ceilings: no-arithmetic streams issued like the shipped kernels -------
     ceilings = None
@@ -461,37 +429,12 @@ def main():
         else:
             shard = {"skipped": "needs %.0f GiB of free HBM on every rank, %.0f free here" % (need / 2**30, free / 2**30)}
 
-    # ---- BASELINE.json configs[3] at its own size: 64 GiB (2^36 nt), two passes and fused, N = 1 only --------
+    # ---- BASELINE.json configs[3] at its own size: 64 GiB (2^36 nt), two passes and fused, N = 1 only (bench_measure.py) ----
     if extras and world == 1:
-        b_len = 1 << 36
-        free, _ = torch.cuda.mem_get_info()
-        key2, keyf = "configs[3] encode + decode as two passes, 64 GiB (2^36 nt)", "configs[3] fused round trip, 64 GiB (2^36 nt)"
-        if free > 150 * 2**30:
-            b_in = torch.empty(b_len, dtype=torch.uint8, device=dev)
-            b_packed = torch.empty(b_len // 32, dtype=torch.int64, device=dev)
-            b_out = torch.empty(b_len, dtype=torch.uint8, device=dev)
-            devutil.fill_random_acgt(b_in, args.seed + 3)
-            be = timed_calls(torch, lambda: cn.n_to_bits_dev(b_in, out=b_packed), 3)
-            bd = timed_calls(torch, lambda: cn.bits_to_n_dev(b_packed, b_len, out=b_out), 3)
-            ok2 = devutil.count_mismatch(b_in, b_out) == 0 if verified is not None else None
-            two_sum = devutil.checksum_words(b_packed) if verified is not None else None
-            b_out.zero_()
-            bf = timed_calls(torch, lambda: cn.round_trip_dev(b_in, out_bits=b_packed, out_n=b_out), 3)
-            okf = (devutil.count_mismatch(b_in, b_out) == 0 and devutil.checksum_words(b_packed) == two_sum) if verified is not None else None
-            t2 = statistics.median(be) + statistics.median(bd)
-            configs[key2] = {"encode_ms": stats_ms(be), "decode_ms": stats_ms(bd), "bytes_per_nt": 2.5, "resident_GiB": 144,
-                             "nt_converted_gnts": round(2 * b_len / (t2 * 1e-3) / 1e9, 1), "achieved_GBs": round(gbs(2.5 * b_len, t2), 1),
-                             "frac": round(gbs(2.5 * b_len, t2) / HBM_PEAK_GBS, 4), "round_trip_verified": ok2}
-            tf = statistics.median(bf)
-            configs[keyf] = {"ms": stats_ms(bf), "bytes_per_nt": 2.25, "resident_GiB": 144,
-                             "nt_converted_gnts": round(2 * b_len / (tf * 1e-3) / 1e9, 1), "achieved_GBs": round(gbs(2.25 * b_len, tf), 1),
-                             "frac": round(gbs(2.25 * b_len, tf) / HBM_PEAK_GBS, 4), "verified_against_two_passes": okf}
-            if verified is not None:
-                verified = verified and ok2 and okf
-            del b_in, b_packed, b_out
-            torch.cuda.empty_cache()
-        else:
-            configs[key2] = configs[keyf] = {"skipped": "needs 150 GiB of free HBM, %.0f GiB free" % (free / 2**30)}
+        rows3, ok3 = measure_config3_64gib(torch, dev, args.seed + 3, verified is not None)
+        configs.update(rows3)
+        if verified is not None and ok3 is not None:
+            verified = verified and ok3
 
     # ---- SURVEY 8 f-1 / f-4 on the driver line (rank 0 at N = 1): 5-letter codec and packed-domain ops at the metric size ---
     codec5 = packed_ops = None

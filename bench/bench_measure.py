@@ -128,6 +128,83 @@ def measure_ceilings(torch, P, d_a, d_b, nbytes, iters=5):
     return rows
 
 
+def measure_configs_1gib(torch, d_in, d_packed, d_out, verify):
+    """BASELINE.json configs[1] / [2] (1 GiB encode / decode) on the first 2^30 nt of the headline's own buffers, and SURVEY
+    8d's size that is not a multiple of 32 (2^30 - 19: thirteen nucleotides in the last word) in the same run.  Average
+    launch duration with 10 launches queued per event pair (what the headline's timed region and rocprofv3 see); the isolated
+    single-launch figure, which also counts the host's event-to-launch gap, is kept beside it."""
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import devutil
+
+    configs = {}
+    m = 1 << 30
+    enc30 = lambda: cn.n_to_bits_dev(d_in[:m], out=d_packed[: m // 32])
+    dec30 = lambda: cn.bits_to_n_dev(d_packed[: m // 32], m, out=d_out[:m])
+    e30, d30 = timed_queued(torch, enc30, 8, 10, warm=2), timed_queued(torch, dec30, 8, 10, warm=2)
+    e30s, d30s = timed_calls(torch, enc30, 10, warm=1), timed_calls(torch, dec30, 10, warm=1)
+    for key, lst, single in (("configs[1] n_to_bits encode, 1 GiB (2^30 nt)", e30, e30s), ("configs[2] bits_to_n decode, 1 GiB (2^30 nt)", d30, d30s)):
+        st = stats_ms(lst)
+        configs[key] = {"ms": st, "timing": "10 launches queued per HIP-event pair, 8 pairs", "gnts": round(m / (st["median"] * 1e-3) / 1e9, 1),
+                        "achieved_GBs": round(gbs(BYTES_PER_NT * m, st["median"]), 1),
+                        "frac": round(gbs(BYTES_PER_NT * m, st["median"]) / HBM_PEAK_GBS, 4),
+                        "isolated_single_launch": {"ms": stats_ms(single), "frac": round(gbs(BYTES_PER_NT * m, statistics.median(single)) / HBM_PEAK_GBS, 4)}}
+    if verify:
+        configs["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]["round_trip_verified"] = devutil.count_mismatch(d_in[:m], d_out[:m]) == 0
+    r = m - 19  # 2^30 - 19 = 32 * (2^25 - 1) + 13
+    if d_in.numel() >= r:
+        encr = lambda: cn.n_to_bits_dev(d_in[:r], out=d_packed[: r // 32 + 1])
+        decr = lambda: cn.bits_to_n_dev(d_packed[: r // 32 + 1], r, out=d_out[:r])
+        er, dr = timed_queued(torch, encr, 8, 10, warm=2), timed_queued(torch, decr, 8, 10, warm=2)
+        assert r % 32 == 13
+        row = {"encode_ms": stats_ms(er), "decode_ms": stats_ms(dr), "timing": "10 launches queued per HIP-event pair, 8 pairs",
+               "launches_per_call": 1,  # head words and ragged end ride in the tile kernel's grid (tests/test_gpu_codec2.py counts the graph nodes)
+               "encode_frac": round(gbs(BYTES_PER_NT * r, statistics.median(er)) / HBM_PEAK_GBS, 4),
+               "decode_frac": round(gbs(BYTES_PER_NT * r, statistics.median(dr)) / HBM_PEAK_GBS, 4),
+               "encode_vs_aligned_2p30": round(statistics.median(er) / statistics.median(e30), 4),
+               "decode_vs_aligned_2p30": round(statistics.median(dr) / statistics.median(d30), 4)}
+        if verify:
+            last = int(d_packed[r // 32].item()) & 0xFFFFFFFFFFFFFFFF
+            row["round_trip_verified"] = devutil.count_mismatch(d_in[:r], d_out[:r]) == 0 and (last >> 26) == 0  # 13 nt used, 38 high bits zero
+        configs["ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)"] = row
+    return configs
+
+
+def measure_config3_64gib(torch, dev, seed, verify):
+    """BASELINE.json configs[3] at its own size: 2^36 nt (64 GiB of ASCII, 144 GiB resident) as two passes and as the fused
+    round trip; ({rows}, all verified | None).  Skips VISIBLY when less than 150 GiB of HBM are free."""
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import devutil
+
+    b_len = 1 << 36
+    free, _ = torch.cuda.mem_get_info()
+    key2, keyf = "configs[3] encode + decode as two passes, 64 GiB (2^36 nt)", "configs[3] fused round trip, 64 GiB (2^36 nt)"
+    if free <= 150 * 2**30:
+        skipped = {"skipped": "needs 150 GiB of free HBM, %.0f GiB free" % (free / 2**30)}
+        return {key2: skipped, keyf: skipped}, None
+    b_in = torch.empty(b_len, dtype=torch.uint8, device=dev)
+    b_packed = torch.empty(b_len // 32, dtype=torch.int64, device=dev)
+    b_out = torch.empty(b_len, dtype=torch.uint8, device=dev)
+    devutil.fill_random_acgt(b_in, seed)
+    be = timed_calls(torch, lambda: cn.n_to_bits_dev(b_in, out=b_packed), 3)
+    bd = timed_calls(torch, lambda: cn.bits_to_n_dev(b_packed, b_len, out=b_out), 3)
+    ok2 = devutil.count_mismatch(b_in, b_out) == 0 if verify else None
+    two_sum = devutil.checksum_words(b_packed) if verify else None
+    b_out.zero_()
+    bf = timed_calls(torch, lambda: cn.round_trip_dev(b_in, out_bits=b_packed, out_n=b_out), 3)
+    okf = (devutil.count_mismatch(b_in, b_out) == 0 and devutil.checksum_words(b_packed) == two_sum) if verify else None
+    t2 = statistics.median(be) + statistics.median(bd)
+    tf = statistics.median(bf)
+    rows = {key2: {"encode_ms": stats_ms(be), "decode_ms": stats_ms(bd), "bytes_per_nt": 2.5, "resident_GiB": 144,
+                   "nt_converted_gnts": round(2 * b_len / (t2 * 1e-3) / 1e9, 1), "achieved_GBs": round(gbs(2.5 * b_len, t2), 1),
+                   "frac": round(gbs(2.5 * b_len, t2) / HBM_PEAK_GBS, 4), "round_trip_verified": ok2},
+            keyf: {"ms": stats_ms(bf), "bytes_per_nt": 2.25, "resident_GiB": 144,
+                   "nt_converted_gnts": round(2 * b_len / (tf * 1e-3) / 1e9, 1), "achieved_GBs": round(gbs(2.25 * b_len, tf), 1),
+                   "frac": round(gbs(2.25 * b_len, tf) / HBM_PEAK_GBS, 4), "verified_against_two_passes": okf}}
+    del b_in, b_packed, b_out
+    torch.cuda.empty_cache()
+    return rows, (bool(ok2 and okf) if verify else None)
+
+
 def measure_codec5(torch, seed, log2_nt, reps=4, queue=4):
     """SURVEY 8 f-1 on the driver line: the 5-letter codec (n_to_bits2 / bits_to_n2, n_to_bits2.rs:37-107) at the metric's
     size on device-resident random ACGTN.  Algorithmic bytes per nucleotide 1 + 8/27 in each direction (27 nt per u64).

@@ -600,7 +600,7 @@ def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
     torch = torch_cuda
     from cute_nucleotides_amd import devutil
 
-    need_free_hbm(166)  # 64 (in) + 16 (packed) + 64 (decoded) + 16 (reference words) GiB + slack
+    need_free_hbm(216)  # 64 (in) + 16 (packed) + 64 (decoded) + 16 (reference words) GiB + slack; 64 + 64 more while the input moves to phase 5
     n_len = (1 << 36) + 2048 * 3 + 77
     d = torch.empty(n_len, dtype=torch.uint8, device="cuda")
     devutil.fill_random_acgt(d, 36)
@@ -623,6 +623,28 @@ def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
         assert np.array_equal(got, oracle.n_to_bits_lut(host_n)), c
     tail = oracle.fill_random_acgt(2048 * 3 + 77, 36, first_nt=1 << 36)  # the ragged end behind the fused tiles
     assert np.array_equal(bits[(1 << 36) // 32 :].cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(tail))
+    # the same 64 GiB through the ANY-ALIGNMENT kernel (round 4: round_trip_window, two launches at this size, head and end as
+    # edge items of the second): input at byte phase 5, packed words at word phase 1, decoded output at byte phase 77 of
+    # buffers that hold a few bytes more; same words as the aligned call above, decoded copy equal to the input
+    want_sum = devutil.checksum_words(bits)
+    del bits
+    torch.cuda.empty_cache()
+    pad_in = torch.empty(n_len + 128, dtype=torch.uint8, device="cuda")
+    v_in = pad_in[5 : 5 + n_len]
+    devutil.fill_random_acgt(pad_in[:n_len], 36)
+    v_in.copy_(d)
+    del d
+    torch.cuda.empty_cache()
+    pad_bits = torch.full(((n_len + 31) // 32 + 8,), -1, dtype=torch.int64, device="cuda")
+    pad_back = torch.full((n_len + 256,), 0x2A, dtype=torch.uint8, device="cuda")
+    v_bits, v_back = pad_bits[1 : 1 + (n_len + 31) // 32], pad_back[77 : 77 + n_len]
+    _, ms2 = _timed_ms(torch, lambda: cn.round_trip_dev(v_in, out_bits=v_bits, out_n=v_back))
+    fullsize(36, ms2, config="configs[3] fused, misaligned (in +5 B, words +8 B, out +77 B)", nt=n_len, gbs=round(2.25 * n_len / ms2 / 1e6, 1))
+    assert devutil.checksum_words(v_bits) == want_sum
+    assert bool((pad_bits[:1] == -1).all()) and bool((pad_bits[1 + (n_len + 31) // 32 :] == -1).all())
+    assert bool((pad_back[:77] == 0x2A).all()) and bool((pad_back[77 + n_len :] == 0x2A).all())
+    for lo in (0, (1 << 35) - 12345, n_len - (1 << 28)):  # decoded copy == input on three 256-MiB windows (torch compares, any alignment)
+        assert torch.equal(v_back[lo : lo + (1 << 28)], v_in[lo : lo + (1 << 28)]), lo
 
 
 # ---- boundary behaviour of the C ABI -------------------------------------------------------
