@@ -79,8 +79,8 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t n_tiles, 
     if constexpr (C == 1) {
         return b;
     } else {
-        static_assert(C == 2 || C == 4, "C is a power of two");
-        constexpr uint32_t cs = C == 2 ? 1 : 2;
+        static_assert(C == 2 || C == 4 || C == 8 || C == 16 || C == 32, "C is a power of two");
+        constexpr uint32_t cs = C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
         const uint32_t gs = xs + cs;  // log2 of the group size X*C
         const uint32_t g = b >> gs;
         if (((g + 1) << gs) > n_tiles) return b;

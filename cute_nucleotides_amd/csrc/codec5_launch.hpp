@@ -62,6 +62,12 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=nt st=sc1, 5 wg/CU", 2 * kWaveBytes5, 64, 5},  // 40
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1, 7 wg/CU", 2 * kWaveBytes5, 64, 7},  // 41
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=nt st=sc1, 8 wg/CU", 2 * kWaveBytes5, 64, 8},  // 42
+    // 32 tiles = 27 whole 4-KiB pages of ASCII: the first group size at which every XCD turn reads whole pages
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s (27 pages per turn), ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 43
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s, ld=nt st=sc1, 12 wg/CU", 2 * kWaveBytes5, 64, 12},  // 44
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s, ld=nt st=sc1, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 45
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 46: 4 KiB of packed OUTPUT per turn
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-8s, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},    // 47
 #endif
 };
 #ifdef CNT_LAB_VARIANTS
@@ -125,6 +131,11 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 4 waves/wg, ld=plain st=sc0|sc1|nt, 5 wg/CU", 2 * kWaveBytes5, 64, 5},  // 43
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt, 7 wg/CU", 2 * kWaveBytes5, 64, 7},  // 44
     {"wave-tiled 2 words/lane, 2 waves/wg, ld=plain st=sc0|sc1|nt, 8 wg/CU", 2 * kWaveBytes5, 64, 8},  // 45
+    // 32 tiles per XCD turn: 27 whole pages of the WRITE stream (and 8 of the read stream) per turn
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 46
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s, ld=plain st=sc0|sc1|nt, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 47
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-8s, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},   // 48
+    {"wave-tiled 2 words/lane, 1 wave/wg, xcd-16s, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 49
 #endif
 };
 #ifdef CNT_LAB_VARIANTS
@@ -146,7 +157,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
     const bool one_wave = encode2_waves(variant) == 1;
     *edges_done = one_wave && total > 0;
     e.tail_first = e.head_words + *done_words;
-    const uint64_t per_launch = max_tiles_per_launch(64) / 8 * 8;  // wave tiles per launch (<= 2^31-1 threads; whole pipeline groups)
+    const uint64_t per_launch = max_tiles_per_launch(64) / 8 * 8;  // wave tiles per launch (<= 2^31-1 threads; whole pipeline groups; the XCD maps are bijections for any count)
     const uint32_t xs = xcd_shift();
     for (uint64_t first = 0; first < total; first += per_launch) {
         const uint64_t n = total - first < per_launch ? total - first : per_launch;
@@ -189,6 +200,9 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
             case 26: CNT_ENC2(1, 2, 0, kSC1); break;
             case 9: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 10: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC0 | kSC1 | kNT, STRICT, 2>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 43: case 44: case 45: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 32>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 46: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 47: hipLaunchKernelGGL((n_to_bits2_wave<1, 2, kNT, kSC1, STRICT, 8>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
 #endif
             default: return 1;
         }
@@ -267,6 +281,9 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
             case 29: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kSC1 | kNT, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 30: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kNT, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
             case 31: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, kSC1, kAll, 4>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 46: case 47: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 32>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 48: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 8>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
+            case 49: hipLaunchKernelGGL((bits_to_n2_wave<1, 2, 0, kAll, 16>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e); break;
 #endif
             default: return 1;
         }
