@@ -188,6 +188,32 @@ int main(int argc, char** argv) {
         }
         cnt_dev_free(d_n); cnt_dev_free(d_bits); cnt_dev_free(d_back);
     }
+    // ---- the enqueue-only multi-GPU device tier through the C++ mirror (one shard on this box's device 0): three
+    // encode -> decode steps queued without a wait in between, one wait, timed per op ------------------------------------
+    {
+        const size_t len = (size_t)1 << 22;
+        const auto n = repeat("ATCG", len / 4);
+        device::set_device(0);
+        device::DeviceBuffer d_n(n.data(), len), d_bits(len / 4), d_back(len);
+        device::ShardedDevQueue q(1, /*timed=*/true);
+        for (int step = 0; step < 3; ++step) {
+            q.enqueue_n_to_bits({&d_n}, {len}, {&d_bits});
+            q.enqueue_bits_to_n({&d_bits}, {len / 32}, {len}, {&d_back});
+        }
+        const auto total = q.wait();
+        float sum = 0.f;
+        for (size_t op = 0; op < 6; ++op) sum += q.op_ms(op)[0];
+        const auto back = d_back.to_vector<uint8_t>(len);
+        const auto words = d_bits.to_vector<uint64_t>(len / 32);
+        bool ok = q.shards() == 1 && total[0] > 0.f && sum > 0.f && sum <= total[0] * 1.01f + 1e-3f && back == n;
+        for (uint64_t w : words) ok = ok && w == 0xD8D8D8D8D8D8D8D8ull;
+        if (!ok) {
+            fprintf(stderr, "ShardedDevQueue mismatch\n");
+            return 2;
+        }
+        printf("%-12s %-34s time: %10.3f us   thrpt: %9.4f GiB/s  (%.3f Gnt/s)\n", "queue", "3 x (encode + decode)/2^22, one wait", total[0] * 1e3 / 6,
+               len / (total[0] * 1e-3 / 6) / (double)(1ull << 30), len / (total[0] * 1e-3 / 6) / 1e9);
+    }
     cnt_shutdown();
     printf("self-check ok: every C-ABI row reproduced its input (host tier, reused outputs, device tier)\n");
     return 0;

@@ -197,7 +197,9 @@ def test_criterion_twin_runs_and_self_checks():
                 ("n_to_bits2", "n_to_bits2_hip"), ("bits_to_n2", "bits_to_n2_hip"),
                 ("n_to_bits", "n_to_bits_hip_dev (resident)"), ("bits_to_n", "bits_to_n_hip_dev (resident)"),
                 ("host-tier", "n_to_bits_hip/2^20"), ("host-tier", "cnt_bits_to_n/2^20 (reused out)"),
-                ("device-tier", "n_to_bits_hip_dev/2^20 (resident)"), ("device-tier", "bits_to_n_hip_dev/2^20 (resident)")):
+                ("device-tier", "n_to_bits_hip_dev/2^20 (resident)"), ("device-tier", "bits_to_n_hip_dev/2^20 (resident)"),
+                ("n_to_bits", "n_to_bits_hip_into"), ("bits_to_n", "bits_to_n_hip_into"), ("host-tier", "n_to_bits_hip_into/2^20"),
+                ("host-tier", "bits_to_n_hip_into/2^20"), ("queue", "3 x (encode + decode)/2^22, one wait")):
         assert key in rows, (key, sorted(rows))
         us, gib = rows[key]
         assert us > 0 and gib > 0
