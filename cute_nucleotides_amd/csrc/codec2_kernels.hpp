@@ -29,7 +29,7 @@
 //     turn) through rounds 1-2; under the residency cap and the store policy adopted AFTER it, plain dispatch order is
 //     0.2-0.9 % faster in encode -> decode steps on five boxes out of five (round 3, bench/xcd_shift_ab.py,
 //     profiles/r03_ab_step_encode_plain_order.log), so encode's default has no map; the pair map is variant 17.  Class
-//     affinity without the consecutive order loses (tried on the 5-letter encoder);
+//     affinity without the consecutive order loses (tried on the 5-letter encoder, profiles/HISTORY.md 5);
 //   * capping residency at ~24 waves per CU (dummy LDS) is worth another 2-3 %.
 // Global accesses go through raw buffer loads/stores: a wave-uniform descriptor
 // per tile gives 32-bit lane offsets under a 64-bit tile base (2^36-nt buffers)

@@ -78,7 +78,7 @@ def test_2bit_codec_instruction_selection(isa):
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"]
     assert t["counts"]["buffer_load_dwordx4"] == 2 and t["counts"]["buffer_store_dword"] == 2
     assert "s_and_saveexec_b64" not in t["counts"] and "v_readfirstlane_b32" not in t["counts"]  # nothing divergent in front of the stores
-    assert t["counts"]["v_mul_lo_u32"] == 8  # y*0x41041: the reference's n_to_bits_mul identity, found by the compiler (DESIGN 4.1)
+    assert t["counts"]["v_mul_lo_u32"] == 8  # y*0x41041: the reference's n_to_bits_mul identity, found by the compiler (DESIGN.md 4)
     assert m["group_segment_fixed_size"] == 0 and t["instructions"] <= 90
     t, w, m = _tile(isa_digest, found, "void cnt::n_to_bits_window<1, 2, 19, false>")
     assert t["load_policies"] == ["nt"] and t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["v_alignbit_b32"] == 2
