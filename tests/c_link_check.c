@@ -21,6 +21,14 @@ int main(void) {
     if (cnt_n_to_bits(NULL, 0, NULL, 0) != CNT_OK) return 7;               /* empty in -> empty out */
     if (cnt_device_count(&count) != CNT_OK) return 8;
     if (count == 0 && cnt_n_to_bits(n, 64, out, 2) != CNT_ENODEV) return 9;  /* no CPU fallback */
+    {   /* the enqueue-only multi-GPU tier from C: no device -> no queue; unknown handles are refused, not dereferenced */
+        void *q = (void *)out;
+        int shards = -1;
+        if (count == 0 && (cnt_sharded_dev_open(1, CNT_QUEUE_TIMED, &q) != CNT_ENODEV || q != NULL)) return 10;
+        if (cnt_sharded_dev_wait((void *)n, NULL) != CNT_EINVAL || cnt_sharded_dev_close((void *)n) != CNT_EINVAL) return 11;
+        if (cnt_sharded_dev_shards((void *)n, &shards) != CNT_EINVAL || cnt_sharded_dev_op_ms((void *)n, 0, NULL) != CNT_EINVAL) return 12;
+        if (cnt_set_tuning("encode", 0) != CNT_EINVAL) return 13;            /* the product library selects nothing at run time */
+    }
     printf("c link ok: abi %d, %d device(s)\n", cnt_abi_version(), count);
     return 0;
 }
