@@ -77,6 +77,7 @@ std::atomic<int> g_decode2_variant{0};
 std::atomic<int> g_small_nt{1 << 17};
 std::atomic<int> g_reduce_xi{1};  // hamming / validate tiles take their pages XCD-interleaved (packed_ops_kernels.hpp)
 std::atomic<int> g_reduce_persistent{1};  // 1 = hamming / validate as one launch of persistent waves (default); 0 = tiles + scratch + second pass (round 1)
+std::atomic<int> g_hamming_order{0};  // load order of hamming_persist's two streams (packed_ops_kernels.hpp): 0 interleaved (shipped), 1 blocks, 2 skewed
 std::atomic<int> g_reduce_fallbacks{0};  // hamming / validate calls that could not get their stream-ordered scratch and ran the generic kernel
 std::atomic<int> g_round_trip_shape{0};  // 0 = <64, 4, 1> (default), 1 = <64, 2, 2> (the first shipped shape), codec2_launch.hpp
 std::atomic<int> g_round_trip_cap{(int)kRoundTripDefaultCap};  // resident one-wave workgroups per CU of the fused round-trip kernel
@@ -421,6 +422,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "reduce_persistent")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_persistent.store(value);
+    } else if (!strcmp(key, "hamming_order")) {
+        if (value < 0 || value > 2) return CNT_EINVAL;
+        g_hamming_order.store(value);
     } else if (!strcmp(key, "reduce_xi")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_xi.store(value);
@@ -466,6 +470,7 @@ int cnt_get_tuning(const char* key, int* value) {
 #ifdef CNT_LAB_VARIANTS
     else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
+    else if (!strcmp(key, "hamming_order")) *value = g_hamming_order.load();
     else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
     else if (!strcmp(key, "reduce_persistent")) *value = g_reduce_persistent.load();
 #else

@@ -175,6 +175,57 @@ __global__ __launch_bounds__(64) void hamming_persist(const uint8_t* __restrict_
     wave_sum_to(total, count);
 }
 
+#ifdef CNT_LAB_VARIANTS
+// Lab build, tuning key "hamming_order": other ways to issue the two streams' loads of a piece.  The shipped kernel above
+// interleaves a[d], b[d]; ORDER 1 = all of a's, then all of b's; ORDER 2 = SKEWED: stream a runs one piece ahead of stream
+// b, so the loads a wave has in flight aim at different offsets of the two operands (a[t + 2G] with b[t + G]).  Hamming
+// is the one kernel whose rate moves with WHERE its operands lie (0.81-0.93 from box to box,
+// profiles/r03_hamming_placement.jsonl): two streams read at equal offsets.
+template <int RUN, int ORDER>
+__global__ __launch_bounds__(64) void hamming_persist_lab(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t n_runs,
+                                                          unsigned long long* __restrict__ count) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t G = gridDim.x, g = blockIdx.x;
+    if (g >= n_runs) return;
+    auto load = [&](const uint8_t* base, uint64_t piece, u32x4(&v)[RUN]) {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(base + piece * (RUN * 1024ull), RUN * 1024);
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) v[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (d * 64 + lane) * 16, 0, kNT));
+    };
+    auto diff = [&](const u32x4(&x)[RUN], const u32x4(&y)[RUN]) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int d = 0; d < RUN; ++d) c += diff_codes32(x[d].x, y[d].x) + diff_codes32(x[d].y, y[d].y) + diff_codes32(x[d].z, y[d].z) + diff_codes32(x[d].w, y[d].w);
+        return c;
+    };
+    const uint64_t last = g + (n_runs - 1 - g) / G * G;  // this wave's last piece; pieces past it are re-reads of it
+    uint64_t total = 0;
+    if constexpr (ORDER == 2) {
+        u32x4 va[RUN], va2[RUN], vb[RUN];
+        load(a, g, va);
+        load(a, g + G <= last ? g + G : last, va2);
+        load(b, g, vb);
+        for (uint64_t t = g; t < n_runs; t += G) {
+            total += diff(va, vb);
+#pragma unroll
+            for (int d = 0; d < RUN; ++d) va[d] = va2[d];
+            load(a, t + 2 * G <= last ? t + 2 * G : last, va2);
+            load(b, t + G <= last ? t + G : last, vb);
+        }
+    } else {
+        u32x4 va[RUN], vb[RUN];
+        load(a, g, va);
+        load(b, g, vb);
+        for (uint64_t t = g; t < n_runs; t += G) {
+            total += diff(va, vb);
+            load(a, t + G <= last ? t + G : last, va);
+            load(b, t + G <= last ? t + G : last, vb);
+        }
+    }
+    wave_sum_to(total, count);
+}
+#endif
+
 // generic / tail: one thread per word from first_word, last word masked to `len`
 __global__ __launch_bounds__(kRedBlock) void hamming_generic(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
                                                              uint64_t len, uint64_t first_word, uint64_t n_words,
