@@ -102,6 +102,10 @@ def main():
     if os.path.exists(f36):  # rocprofv3 --kernel-trace of a 2^36-nt fused round trip (BASELINE.json configs[3]), one row per (kernel, grid)
         stats_by_grid(os.path.join(src, "stats_fused36", "fused36_kernel_trace.csv"), os.path.join(dst, tag + "_fused_2p36_kernel_stats.csv"))
         shutil.copy(os.path.join(src, "fused36_under_rocprof.jsonl"), os.path.join(dst, tag + "_fused_2p36_under_rocprof.jsonl"))
+    fany = os.path.join(src, "stats_fused_any", "fusedany_kernel_trace.csv")
+    if os.path.exists(fany):  # cnt_round_trip_dev at twelve pointer-offset triples: round_trip_window beside round_trip_stream
+        stats_by_grid(fany, os.path.join(dst, tag + "_fused_any_alignment_kernel_stats.csv"))
+        shutil.copy(os.path.join(src, "fused_any_under_rocprof.jsonl"), os.path.join(dst, tag + "_fused_any_alignment_under_rocprof.jsonl"))
     n = 1 << log2_nt
     summary = traffic_summary(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"),
                               os.path.join(src, "pmc_write", "pmc_counter_collection.csv"), n, tag)

@@ -21,6 +21,10 @@ echo "stats rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_fused36" -o fused36 -- \
     python "$REPO/bench/bench_round_trip.py" --log2-nt 36 --caps 8 --rounds 3 --iters 2 > "$OUT/fused36_under_rocprof.jsonl" 2> "$OUT/stats_fused36.err"
 echo "stats fused36 rc=$?"
+# 1c. the fused round trip off the 128-B grid (round_trip_window) beside the aligned kernel, 2^34 nt
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_fused_any" -o fusedany -- \
+    python "$REPO/bench/align_round_trip.py" --log2-nt 34 --rounds 2 --queue 2 > "$OUT/fused_any_under_rocprof.jsonl" 2> "$OUT/stats_fused_any.err"
+echo "stats fused any-alignment rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- \
     python "$REPO/bench/pmc_workload.py" > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch rc=$?"
