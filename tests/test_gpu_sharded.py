@@ -280,6 +280,48 @@ def test_enqueue_only_queue_runs_steps_ahead_and_matches_the_oracle(L, oracle, a
     assert torch.cuda.current_device() == 0
 
 
+def test_queues_of_several_threads_are_independent(L, oracle, alias):
+    """Four host threads, each with its own two-shard queue (and, interleaved, the synchronous entry points, which use a
+    queue cached per calling thread): every thread's results equal the oracle's, no thread waits on another's streams."""
+    import threading
+
+    import torch
+
+    from cute_nucleotides_amd import sharding
+
+    sizes = [(1 << 19) + 7, 40000]
+    bad = []
+
+    def body(tid):
+        try:
+            torch.cuda.set_device(0)
+            host = [oracle.fill_random_acgt(s, 4000 + 10 * tid + k) for k, s in enumerate(sizes)]
+            d_in = [torch.from_numpy(h).cuda() for h in host]
+            d_pk = [torch.zeros((s + 31) // 32, dtype=torch.int64, device="cuda") for s in sizes]
+            d_out = [torch.zeros(s, dtype=torch.uint8, device="cuda") for s in sizes]
+            torch.cuda.synchronize()
+            with sharding.DevQueue(2, timed=(tid % 2 == 0)) as q:
+                for _ in range(5):
+                    q.n_to_bits(d_in, d_pk)
+                    q.bits_to_n(d_pk, sizes, d_out)
+                q.wait()
+            for k, h in enumerate(host):
+                if not np.array_equal(d_pk[k].cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(h)) or not np.array_equal(d_out[k].cpu().numpy(), h):
+                    bad.append((tid, k, "queue"))
+            outs = sharding.n_to_bits_sharded_dev(d_in)  # the synchronous form: this thread's cached queue
+            for k, h in enumerate(host):
+                if not np.array_equal(outs[k].cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(h)):
+                    bad.append((tid, k, "sync"))
+        except Exception as exc:  # noqa: BLE001
+            bad.append((tid, repr(exc)))
+
+    ts = [threading.Thread(target=body, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad, bad
+    assert L.cnt_shutdown() == 0  # releases the calling thread's cached queues too
+
+
 def test_enqueue_only_queue_error_paths(L, alias):
     import torch
 
