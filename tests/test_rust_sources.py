@@ -42,3 +42,40 @@ def test_every_hip_item_the_harness_calls_exists_in_the_binding():
         assert re.search(r"pub fn %s\b" % method, hip), method
     cargo = open(os.path.join(ROOT, "rust", "Cargo.toml")).read()
     assert 'name = "bench_n_to_bits"' in cargo and "harness = false" in cargo and "criterion" not in cargo
+
+
+def test_binding_keeps_the_reference_signatures_and_is_well_formed():
+    """The four mirrored functions carry the reference's signatures to the letter (n_to_bits.rs:34,51; n_to_bits2.rs:37,78),
+    the `_into` forms and the queue type added in round 4 are there, every `unsafe` call site checks the status, and both
+    Rust files are at least lexically well formed (balanced delimiters outside strings, chars and comments) -- what can be
+    said without a compiler."""
+    hip = open(os.path.join(ROOT, "rust", "src", "hip.rs")).read()
+    for sig in (r"pub fn n_to_bits_hip\(n: &\[u8\]\) -> Vec<u64> \{", r"pub fn bits_to_n_hip\(bits: &\[u64\], len: usize\) -> Vec<u8> \{",
+                r"pub fn n_to_bits2_hip\(n: &\[u8\]\) -> Vec<u64> \{", r"pub fn bits_to_n2_hip\(bits: &\[u64\], len: usize\) -> Vec<u8> \{",
+                r"pub fn n_to_bits_hip_into\(n: &\[u8\], res: &mut Vec<u64>\) \{", r"pub fn bits_to_n_hip_into\(bits: &\[u64\], len: usize, res: &mut Vec<u8>\) \{",
+                r"pub fn n_to_bits2_hip_into\(n: &\[u8\], res: &mut Vec<u64>\) \{", r"pub fn bits_to_n2_hip_into\(bits: &\[u64\], len: usize, res: &mut Vec<u8>\) \{",
+                r"pub struct ShardedDevQueue \{", r"impl Drop for ShardedDevQueue \{", r"pub fn enqueue_n_to_bits\(&mut self,", r"pub fn enqueue_bits_to_n\(&mut self,",
+                r"pub fn wait\(&mut self\) -> Vec<f32> \{"):
+        assert re.search(sig, hip), sig
+    # the reference's panic text wherever a decoder checks `len` (n_to_bits.rs:52-54)
+    assert hip.count('panic!("The length is greater than the number of nucleotides!")') >= 6
+    # every call of a status-returning C symbol goes through check(...) (the three Drop impls and the bool probe excepted)
+    calls = re.findall(r"\b(cnt_\w+)\(", hip.split('extern "C" {', 1)[1].split("}", 1)[1])
+    body = hip.split("fn check(status: c_int)", 1)[1]
+    for name in set(calls) - {"cnt_strerror", "cnt_words_for", "cnt_words2_for"}:
+        sites = [m.start() for m in re.finditer(r"\b%s\(" % name, body)]
+        for s in sites:
+            line = body[body.rfind("\n", 0, s) + 1 : body.find("\n", s)]
+            assert "check(" in line or "fn drop" in body[max(0, s - 120) : s] or "== 0" in line, (name, line.strip())
+    for rel in (("rust", "src", "hip.rs"), ("rust", "benches", "bench_n_to_bits.rs"), ("rust", "src", "lib.rs"), ("rust", "build.rs")):
+        text = open(os.path.join(ROOT, *rel)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r'b?"(?:\\.|[^"\\])*"', '""', text)
+        text = re.sub(r"b?'(?:\\.|[^'\\])'", "' '", text)
+        stack = []
+        for ch in text:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in ")]}":
+                assert stack and "([{".index(stack.pop()) == ")]}".index(ch), rel
+        assert not stack, rel
