@@ -39,16 +39,22 @@ class CopyPool {
     // condition variable -- inside a pipelined call it never sleeps, so a copy starts within a microsecond instead of the
     // 20-50 us of a condition-variable wake-up (which made 8 threads SLOWER than 4 in the first version of this pool).
     void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false) {
+        if (bytes < kMinPar) {  // small copies never start (or wake) the team
+            memcpy(dst, src, bytes);
+            return;
+        }
         const int all = threads();
         const int T = fresh_pages ? all : std::max(1, (all + 1) / 2);  // warm copies use the configured team, fresh ones twice that
-        if (bytes < kMinPar || T <= 1) {
+        if (T <= 1) {
             memcpy(dst, src, bytes);
             return;
         }
         const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
         // blocks are cut on multiples of the block size of the DESTINATION address (the first one is short): with 2-MiB
         // blocks a huge page of a fresh output is faulted in by ONE thread instead of being fought over by eight
-        const size_t blk = fresh_pages ? kFreshBlock : kWarmBlock;
+        // (round 4) copies of up to 1 MiB -- the chunks of mid-size calls, 2^20..2^22 nt -- in 256-KiB blocks: with 1-MiB blocks a
+        // 1-MiB copy was ONE block, i.e. one thread (larger copies keep 1-MiB blocks: 256-KiB blocks cost 4-MiB copies 5-12 %)
+        const size_t blk = fresh_pages ? kFreshBlock : bytes <= kSmallCopy ? kSmallBlock : kWarmBlock;
         const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
         const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
         // Publication order: the block counter moves to generation g FIRST -- from here on nobody can take a
@@ -69,7 +75,9 @@ class CopyPool {
         job_nblocks_.store(nblocks, std::memory_order_relaxed);
         job_team_.store(T, std::memory_order_relaxed);
         gen_.store(g, std::memory_order_seq_cst);
-        if (sleepers_.load(std::memory_order_seq_cst) > 0) {
+        // helpers that are still spinning (the previous copy was < 150 us ago) join at once; sleeping ones are woken only for
+        // copies worth a 20-50 us wake-up -- a 1-MiB copy of an isolated small call is the caller's alone, as it always was
+        if (bytes > kSmallCopy && sleepers_.load(std::memory_order_seq_cst) > 0) {
             std::lock_guard<std::mutex> lk(m_);
             cv_work_.notify_all();
         }
@@ -110,6 +118,7 @@ class CopyPool {
     // per 1-GiB encode); copies into fresh pages in 2-MiB blocks cut on the DESTINATION's 2-MiB grid, so that one thread
     // faults a transparent huge page in instead of eight fighting over it (1-GiB decode into a fresh buffer 35 -> 24 ms).
     static constexpr size_t kMinPar = (size_t)512 << 10, kWarmBlock = (size_t)1 << 20, kFreshBlock = (size_t)2 << 20;
+    static constexpr size_t kSmallCopy = (size_t)1 << 20, kSmallBlock = (size_t)256 << 10;
     static constexpr int kSpinUs = 150;
     static void cpu_relax() {
 #if defined(__x86_64__)
