@@ -55,7 +55,7 @@ for _p in (ROOT, os.path.join(ROOT, "bench")):
 # timing loops and the extra blocks of the N = 1 line; bench_single_process.py = `--gpus N` without a launcher.  This file
 # keeps the arguments, the CPU-baseline leg (the only code allowed to touch oracle/), the timed region and the JSON line.
 from bench_measure import (BYTES_PER_NT, HBM_PEAK_GBS, HOST_TIER_LOG2, crossover, gbs, gpu_numa_node, host_placement,  # noqa: E402,F401
-                           load_probes, measure_ceilings, measure_codec5, measure_config3_64gib, measure_configs_1gib, measure_host_tier,
+                           load_probes, measure_ceilings, measure_codec5, host_tier_block, measure_config3_64gib, measure_configs_1gib, measure_host_tier,
                            measure_packed_ops, measure_pcie,
                            measure_traffic_live, numpy_pack, physical_cores, sockets, stats_ms, timed_calls, timed_queued)
 
@@ -602,42 +602,8 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             if extras:
-                rows = measure_host_tier(args.seed)
-                pcie = measure_pcie(torch)
                 cpu_rows = line["cpu_baseline"].get("reference_faithful_GiBs_1thread_alloc_inclusive") or {}
-                names = ("n_to_bits_hip reused out", "bits_to_n_hip reused out", "n_to_bits_hip fresh out", "bits_to_n_hip fresh out")
-                big = rows["2^%d" % HOST_TIER_LOG2[-1]]
-                # encode moves N bytes up and N/4 down (full duplex: the H2D leg bounds it), decode N/4 up and N down (the D2H leg)
-                frac = {nm: round(big[nm] / pcie["h2d_GiBs" if nm.startswith("n_to_bits") else "d2h_GiBs"], 4) for nm in names}
-                line["host_tier"] = {
-                    "pcie_ceiling": dict(pcie, what="pinned hipMemcpy of 1 GiB, median of 5, same run"),
-                    "frac_of_pcie_ceiling_at_2^%d" % HOST_TIER_LOG2[-1]: frac,
-                    "timing_conventions": {
-                        "what": "the same host-slice call under the three ways a caller can time it, microseconds per call: `drop_inside` = result "
-                                "allocated AND the previous one freed inside the timed loop (the reference's harness, benches/bench_n_to_bits.rs:6-7; on "
-                                "this host munmap alone is ~47 ms per GiB of huge pages, 120 ms per GiB of 4-KiB pages, with or without HIP in the "
-                                "process: bench/munmap_lab.cpp), `drop_outside` = allocated inside, freed later, `into` = the `_into` form of the "
-                                "mirrors (n_to_bits_hip_into / bits_to_n_hip_into: the caller keeps the vector; rust/src/hip.rs, cute_nucleotides.hpp, "
-                                "n_to_bits.py)",
-                        **{"2^%d" % k: {fn: {"drop_inside_us": rows["2^%d" % k][fn + " fresh out us"],
-                                             "drop_outside_us": rows["2^%d" % k].get(fn + " fresh out, dropped later us"),
-                                             "into_us": rows["2^%d" % k][fn + "_into us"]}
-                                        for fn in ("n_to_bits_hip", "bits_to_n_hip")} for k in HOST_TIER_LOG2 if k >= 26}},
-                    "fresh_over_reused_at_2^%d" % HOST_TIER_LOG2[-1]: {
-                        "what": "time of a call whose output is allocated inside it over the time into a reused output (see timing_conventions)",
-                        "n_to_bits_hip": {"drop_inside": round(big["n_to_bits_hip fresh out us"] / big["n_to_bits_hip reused out us"], 3),
-                                          "drop_outside": round(big["n_to_bits_hip fresh out, dropped later us"] / big["n_to_bits_hip reused out us"], 3),
-                                          "into": round(big["n_to_bits_hip_into us"] / big["n_to_bits_hip reused out us"], 3)},
-                        "bits_to_n_hip": {"drop_inside": round(big["bits_to_n_hip fresh out us"] / big["bits_to_n_hip reused out us"], 3),
-                                          "drop_outside": round(big["bits_to_n_hip fresh out, dropped later us"] / big["bits_to_n_hip reused out us"], 3),
-                                          "into": round(big["bits_to_n_hip_into us"] / big["bits_to_n_hip reused out us"], 3)}},
-                    "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread; "
-                            "`fresh out` allocates the output inside the timed call like the reference's functions do; microseconds per call "
-                            "at 2^k nt (GiB/s of the fresh-out calls are in the crossover table)",
-                    "log2_nt": list(HOST_TIER_LOG2),
-                    "placement": dict(rows["placement"], gpu_numa_node=gpu_numa_node(ident.get("pci_bus_id"))),
-                    "us_per_call": {nm: [rows["2^%d" % k][nm + " us"] for k in HOST_TIER_LOG2] for nm in names},
-                    "crossover_vs_one_cpu_thread": crossover(rows, cpu_rows)}
+                line["host_tier"] = host_tier_block(torch, args.seed, cpu_rows, ident.get("pci_bus_id"))  # bench/bench_measure.py
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -392,6 +392,47 @@ def measure_host_tier(seed):
     return rows
 
 
+def host_tier_block(torch, seed, cpu_rows, pci_bus_id):
+    """The `host_tier` block of the N = 1 line: the drop-in host-slice calls at the crossover table's sizes (reused / `_into` /
+    fresh outputs), the same-run PCIe ceilings and the fraction of them reached at 1 GiB, the three timing conventions side by
+    side, where the buffers lie, and the crossover against one CPU thread of the reference's fastest AVX2 path."""
+    rows = measure_host_tier(seed)
+    pcie = measure_pcie(torch)
+    names = ("n_to_bits_hip reused out", "bits_to_n_hip reused out", "n_to_bits_hip fresh out", "bits_to_n_hip fresh out")
+    big = rows["2^%d" % HOST_TIER_LOG2[-1]]
+    # encode moves N bytes up and N/4 down (full duplex: the H2D leg bounds it), decode N/4 up and N down (the D2H leg)
+    frac = {nm: round(big[nm] / pcie["h2d_GiBs" if nm.startswith("n_to_bits") else "d2h_GiBs"], 4) for nm in names}
+    return {
+        "pcie_ceiling": dict(pcie, what="pinned hipMemcpy of 1 GiB, median of 5, same run"),
+        "frac_of_pcie_ceiling_at_2^%d" % HOST_TIER_LOG2[-1]: frac,
+        "timing_conventions": {
+            "what": "the same host-slice call under the three ways a caller can time it, microseconds per call: `drop_inside` = result "
+                    "allocated AND the previous one freed inside the timed loop (the reference's harness, benches/bench_n_to_bits.rs:6-7; on "
+                    "this host munmap alone is ~47 ms per GiB of huge pages, 120 ms per GiB of 4-KiB pages, with or without HIP in the "
+                    "process: profiles/r03_munmap_lab.log), `drop_outside` = allocated inside, freed later, `into` = the `_into` form of the "
+                    "mirrors (n_to_bits_hip_into / bits_to_n_hip_into: the caller keeps the vector; rust/src/hip.rs, cute_nucleotides.hpp, "
+                    "n_to_bits.py)",
+            **{"2^%d" % k: {fn: {"drop_inside_us": rows["2^%d" % k][fn + " fresh out us"],
+                                 "drop_outside_us": rows["2^%d" % k].get(fn + " fresh out, dropped later us"),
+                                 "into_us": rows["2^%d" % k][fn + "_into us"]}
+                            for fn in ("n_to_bits_hip", "bits_to_n_hip")} for k in HOST_TIER_LOG2 if k >= 26}},
+        "fresh_over_reused_at_2^%d" % HOST_TIER_LOG2[-1]: {
+            "what": "time of a call whose output is allocated inside it over the time into a reused output (see timing_conventions)",
+            "n_to_bits_hip": {"drop_inside": round(big["n_to_bits_hip fresh out us"] / big["n_to_bits_hip reused out us"], 3),
+                              "drop_outside": round(big["n_to_bits_hip fresh out, dropped later us"] / big["n_to_bits_hip reused out us"], 3),
+                              "into": round(big["n_to_bits_hip_into us"] / big["n_to_bits_hip reused out us"], 3)},
+            "bits_to_n_hip": {"drop_inside": round(big["bits_to_n_hip fresh out us"] / big["bits_to_n_hip reused out us"], 3),
+                              "drop_outside": round(big["bits_to_n_hip fresh out, dropped later us"] / big["bits_to_n_hip reused out us"], 3),
+                              "into": round(big["bits_to_n_hip_into us"] / big["bits_to_n_hip reused out us"], 3)}},
+        "what": "the drop-in host-slice calls (H2D + kernel + D2H inside; PCIe-bound, never `value`), one calling thread; "
+                "`fresh out` allocates the output inside the timed call like the reference's functions do; microseconds per call "
+                "at 2^k nt (GiB/s of the fresh-out calls are in the crossover table)",
+        "log2_nt": list(HOST_TIER_LOG2),
+        "placement": dict(rows["placement"], gpu_numa_node=gpu_numa_node(pci_bus_id)),
+        "us_per_call": {nm: [rows["2^%d" % k][nm + " us"] for k in HOST_TIER_LOG2] for nm in names},
+        "crossover_vs_one_cpu_thread": crossover(rows, cpu_rows)}
+
+
 def host_placement(arr):
     """Where a host array's pages lie (NUMA nodes, share in transparent huge pages) and which CPU the caller is on: the host
     tier's 1-GiB rows move by 15 % with these (profiles/r03_host_numa_placement.jsonl), so the line says what it ran on."""
