@@ -20,7 +20,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log2-nt", type=int, default=34)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--queue", type=int, default=4)
+ap.add_argument("--window-map", type=int, default=-1, help="lab build: tile map of round_trip_window (0 plain, 1 XCD pairs, 2 XCD quads); -1 = product library")
+ap.add_argument("--cap", type=int, default=-1, help="lab build: resident workgroups per CU")
 a = ap.parse_args()
+if a.window_map >= 0 or a.cap >= 0:
+    from cute_nucleotides_amd import _lib
+
+    _lib.use_lab_build()
+    if a.window_map >= 0:
+        devutil.set_tuning("round_trip_window_map", a.window_map)
+    if a.cap >= 0:
+        devutil.set_tuning("round_trip_cap", a.cap)
 n = 1 << a.log2_nt
 pad = 16384
 b_in = torch.empty(n + pad, dtype=torch.uint8, device="cuda")

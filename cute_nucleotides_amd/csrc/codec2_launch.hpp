@@ -288,7 +288,7 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
 // Same shape, policies and residency cap as the aligned kernel; the cap's dynamic LDS doubles as the 1280-B exchange slab.
 template <bool STRICT>
 void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap,
-                           RoundTripEdgesAny e, hipStream_t s) {
+                           RoundTripEdgesAny e, hipStream_t s, int map = 0) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 2;
     const uint32_t lds = std::max(lds_for_cap(cap), kRoundTripAnySlab);
     const uint32_t xs = xcd_shift();
@@ -296,6 +296,20 @@ void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2,
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         e.groups = first + n_tiles == total_tiles ? edge_groups(items, 64, n_tiles) : 0u;  // the edges ride in the last launch
+#ifdef CNT_LAB_VARIANTS  // tuning key "round_trip_window_map": 1 = XCD pairs, 2 = XCD quads (the read-ahead of 1 / 3 of 2 / 4 tiles stays in one L2)
+        if (map == 1) {
+            hipLaunchKernelGGL((round_trip_window<2, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, base + first * kRoundTripAnyTile,
+                               packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile, (uint32_t)n_tiles, phase, phase2, xs, e);
+            continue;
+        }
+        if (map == 2) {
+            hipLaunchKernelGGL((round_trip_window<4, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, base + first * kRoundTripAnyTile,
+                               packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile, (uint32_t)n_tiles, phase, phase2, xs, e);
+            continue;
+        }
+#else
+        (void)map;
+#endif
         hipLaunchKernelGGL((round_trip_window<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kRoundTripAnyTile, packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile,
                            (uint32_t)n_tiles, phase, phase2, xs, e);

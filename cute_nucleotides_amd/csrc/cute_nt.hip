@@ -88,6 +88,8 @@ inline int tune_decode2() { return g_decode2_variant.load(std::memory_order_rela
 inline size_t tune_small_nt() { return (size_t)g_small_nt.load(std::memory_order_relaxed); }
 inline int tune_round_trip_shape() { return g_round_trip_shape.load(std::memory_order_relaxed); }
 inline uint32_t tune_round_trip_cap() { return (uint32_t)g_round_trip_cap.load(std::memory_order_relaxed); }
+std::atomic<int> g_round_trip_window_map{0};  // tile map of the any-alignment fused kernel: 0 plain order (shipped), 1 XCD pairs, 2 XCD quads
+inline int tune_round_trip_window_map() { return g_round_trip_window_map.load(std::memory_order_relaxed); }
 #else
 constexpr int tune_encode() { return 0; }
 constexpr int tune_decode() { return 0; }
@@ -96,6 +98,7 @@ constexpr int tune_decode2() { return 0; }
 constexpr size_t tune_small_nt() { return (size_t)1 << 17; }
 constexpr int tune_round_trip_shape() { return 0; }
 constexpr uint32_t tune_round_trip_cap() { return kRoundTripDefaultCap; }
+constexpr int tune_round_trip_window_map() { return 0; }
 #endif
 
 inline unsigned generic_grid(uint64_t items) {
@@ -419,6 +422,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_shape")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_round_trip_shape.store(value);
+    } else if (!strcmp(key, "round_trip_window_map")) {
+        if (value < 0 || value > 2) return CNT_EINVAL;
+        g_round_trip_window_map.store(value);
     } else if (!strcmp(key, "reduce_persistent")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_persistent.store(value);
