@@ -580,15 +580,44 @@ def test_fused_round_trip_alignment_matrix(cn, oracle, torch_cuda, strict):
                     assert (b[: 128 + bo] == 0x2A).all() and (b[128 + bo + n_len :] == 0x2A).all(), (n_len, io, po, bo)
                     assert np.array_equal(p[8 + po : 8 + po + words].view(np.uint64), want_bits), (n_len, io, po, bo)
                     assert np.array_equal(b[128 + bo : 128 + bo + n_len], want_back), (n_len, io, po, bo)
-    if not strict:  # CNT_TAIL_LUT through the window kernel: the SIMD encoders to the letter on arbitrary bytes
-        raw = rng.integers(0, 256, 100003, dtype=np.uint8)
-        view = ibuf[7 : 7 + raw.size]
-        view.copy_(torch.from_numpy(raw))
-        bits, back = cn.round_trip_dev(view, out_bits=pbuf[1 : 1 + (raw.size + 31) // 32], out_n=bbuf[3 : 3 + raw.size], tail_lut=True)
-        want = oracle.n_to_bits_bitextract(raw[: raw.size // 32 * 32])
-        tail = oracle.n_to_bits_lut(raw[raw.size // 32 * 32 :])
-        assert np.array_equal(bits.cpu().numpy().view(np.uint64), np.concatenate([want, tail]))
-        assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(np.concatenate([want, tail]), raw.size))
+    if not strict:  # CNT_TAIL_LUT through the window kernel: the SIMD encoders to the letter on arbitrary bytes -- bit extraction
+        # on whole 32-nt blocks, BYTE_LUT on the final partial word, whose first letters a tile's last packed dword must not
+        # reach (every residue of the length mod 32, several phases of all three pointers)
+        for n_len in [100003 + k for k in range(32)] + [4096 * 3 + 400 + k for k in (1, 17, 18, 30, 31)]:
+            raw = rng.integers(0, 128, n_len, dtype=np.uint8)  # the reference indexes BYTE_LUT[128]: 7-bit input
+            whole = raw.size // 32 * 32
+            want = np.concatenate([oracle.n_to_bits_bitextract(raw[:whole]), oracle.n_to_bits_lut(raw[whole:])]) if raw.size % 32 else oracle.n_to_bits_bitextract(raw)
+            for io, po, bo in ((7, 1, 3), (0, 0, 1), (100, 5, 2049), (16, 0, 16)):
+                view = ibuf[io : io + raw.size]
+                view.copy_(torch.from_numpy(raw))
+                bits, back = cn.round_trip_dev(view, out_bits=pbuf[po : po + (raw.size + 31) // 32], out_n=bbuf[bo : bo + raw.size], tail_lut=True)
+                assert np.array_equal(bits.cpu().numpy().view(np.uint64), want), (n_len, io, po, bo)
+                assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(want, raw.size)), (n_len, io, po, bo)
+
+
+def test_fused_tail_lut_never_lets_a_tile_touch_the_final_partial_word(cn, oracle, torch_cuda):
+    """CNT_TAIL_LUT through round_trip_window: the final partial word is BYTE_LUT's (n_to_bits.rs:109-111) in BOTH outputs --
+    its packed codes and its decoded letters -- and everything in front of it is bit extraction.  Whether the last tile's
+    letters could reach into that word depends on all three pointer phases and the length at once (a simulation of the
+    launcher's arithmetic over every phase found 370 000 such cases before the launcher was told where the word starts):
+    twelve of them, input byte phase / packed-word phase / output byte phase / length, each with the 31 lengths around it;
+    arbitrary 7-bit bytes."""
+    torch = torch_cuda
+    rng = np.random.default_rng(63)
+    big = rng.integers(0, 128, 5 * 4096 + 256, dtype=np.uint8)
+    ib = torch.zeros(big.size + 512, dtype=torch.uint8, device="cuda")
+    pb = torch.zeros(big.size // 32 + 16, dtype=torch.int64, device="cuda")
+    bb = torch.zeros(big.size + 4096, dtype=torch.uint8, device="cuda")
+    assert ib.data_ptr() % 128 == 0 and pb.data_ptr() % 64 == 0 and bb.data_ptr() % 128 == 0  # the phases below are absolute
+    for io, po, bo, n0 in ((100, 7, 24, 12412), (5, 3, 54, 12507), (100, 7, 54, 12380), (100, 7, 58, 12380), (37, 3, 89, 12475), (1, 1, 27, 12543),
+                           (100, 7, 62, 12380), (5, 3, 62, 12507), (5, 3, 55, 12507), (1, 3, 22, 12543), (37, 3, 62, 12507), (1, 3, 88, 12479)):
+        ib[io : io + big.size].copy_(torch.from_numpy(big))
+        for n_len in range(n0 - 15, n0 + 16):
+            raw, whole = big[:n_len], n_len // 32 * 32
+            want = np.concatenate([oracle.n_to_bits_bitextract(raw[:whole]), oracle.n_to_bits_lut(raw[whole:])]) if n_len % 32 else oracle.n_to_bits_bitextract(raw)
+            bits, back = cn.round_trip_dev(ib[io : io + n_len], out_bits=pb[po : po + (n_len + 31) // 32], out_n=bb[bo : bo + n_len], tail_lut=True)
+            assert np.array_equal(bits.cpu().numpy().view(np.uint64), want), (io, po, bo, n_len)
+            assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(want, n_len)), (io, po, bo, n_len)
 
 
 def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
