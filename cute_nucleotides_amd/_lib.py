@@ -88,6 +88,7 @@ SIGNATURES = {
     "cnt_check_device_range": (_int, [ctypes.c_void_p, ctypes.c_size_t, _int]),
     "cnt_test_alias_devices": (_int, [_int]),
     "cnt_test_advise_output": (_int, [_vp, _sz]),
+    "cnt_test_round_trip_plan": (_int, [_u64, _u64, _u64, _u64, _uint, ctypes.POINTER(_u64)]),
 }
 
 _libs = {}          # "product" / "lab" -> loaded CDLL

@@ -535,6 +535,23 @@ int cnt_check_device_range(const void* p, size_t bytes, int device) {
 }
 
 int cnt_test_alias_devices(int on) { return g_alias_devices.exchange(on ? 1 : 0); }
+int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t* out) {
+    if (!out || (a_bits & 7) || (flags & ~kEncodeFlags)) return CNT_EINVAL;
+    const bool strict = (flags & CNT_STRICT_LUT) != 0;
+    const uint64_t lut_from = lut_from_of(n_len, flags, 32);
+    const uint64_t limit = lut_from != kNoLutWord && !strict ? n_len & ~(uint64_t)31 : n_len;
+    const bool fast = !(a_n & 127) && !(a_bits & 127) && !(a_back & 127) && n_len >= kRoundTripTile;
+    const RoundTripPlan p = fast ? RoundTripPlan{} : round_trip_plan((uintptr_t)a_n, (uintptr_t)a_bits, (uintptr_t)a_back, n_len, limit);
+    out[0] = fast ? 1 : 0;  // 1: the aligned kernel (round_trip_stream) takes the call
+    out[1] = p.t0;
+    out[2] = p.p0;
+    out[3] = p.tiles;
+    out[4] = (uint64_t)p.w0;
+    out[5] = p.phase;
+    out[6] = p.phase2;
+    out[7] = kRoundTripAnySlackVecs;
+    return CNT_OK;
+}
 int cnt_test_advise_output(void* out, size_t bytes) {
     if (!out) return CNT_EINVAL;
     advise_huge_output(out, bytes);

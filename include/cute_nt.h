@@ -324,6 +324,14 @@ int cnt_test_alias_devices(int on);
  * with that output would, without any device work: lets a box without a GPU check what the library does -- and does not
  * do -- to caller memory (tests/test_hugepage_scope.py). */
 int cnt_test_advise_output(void *out, size_t bytes);
+/* The launch plan cnt_round_trip_dev would use for buffers at these ADDRESSES (nothing is dereferenced, no device needed):
+ * out[0] = 1 if the aligned kernel takes the call, else 0 and out[1..6] = t0 (first nucleotide a tile decodes), p0 (first
+ * packed dword a tile writes), tiles, w0 (nucleotide index of the aligned window's first byte), phase, phase2 (where t0 and
+ * 16 p0 sit in the window); out[7] = 16-byte vectors of the window a tile may read behind its 4 KiB.  Lets the CPU box check
+ * the arithmetic for EVERY pointer phase (tests/test_round_trip_plan.py): windows inside the buffer, funnel reads inside
+ * the slab, every letter and packed dword owned by exactly one of tiles / edge items, tiles off the final partial word
+ * under CNT_TAIL_LUT. */
+int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t *out);
 
 #ifdef __cplusplus
 }
