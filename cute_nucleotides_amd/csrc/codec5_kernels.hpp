@@ -439,6 +439,95 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------
+// PAGE tiles for the decoder (round 4).  The word tiles above give every wave 3456 B = 27 lines of the ASCII stream, so
+// each 4-KiB page of the stream that carries 77 % of the bytes is written by two waves; bench/codec5_page_lab.hip prices
+// the two address patterns without arithmetic: one wave per whole page of the WRITE stream (four full 1-KiB stores -- the
+// 2-bit decoder's shape) and a ragged 1213.6-B piece of the packed stream runs 3 % faster than the word tiles.  Here
+// tile t owns letters [4096 t, 4096 t + 4096) of the launch: its first word is w0 = 4096 t / 27, the page starts r =
+// 4096 t - 27 w0 letters into it, and 153 words (three rounds of 64 lanes, the third with 25) always cover r + 4096 <=
+// 4122 letters.  Word idx is expanded exactly as in bits_to_n2_wave but lands at slab byte 27 idx + 32 - r, which puts the
+// page's first letter on slab byte 32 for every r: the page leaves with four aligned 16-B reads per lane.  Rounds keep
+// one byte phase (1728 B per round is dword aligned); what lane 0 of round j shares with lane 63 of round j - 1 comes
+// through one v_readlane.  Words past the end of the packed array read as 0 through the descriptor; their letters lie
+// behind the page.
+// ---------------------------------------------------------------------------
+constexpr int kPageNt5 = 4096, kPageWords5 = 153, kPageSlabDwords5 = (32 + 27 * 192 + 3) / 4 + 4;
+struct Decode2PageEdges {
+    const uint64_t* bits;
+    uint8_t* out;
+    uint64_t len, head_nt, tail_from;  // letters [0, head_nt) and [tail_from, len) belong to the edge items
+    uint32_t groups;
+};
+// letters [lo, hi) n word w's 27 with byte stores
+__device__ __forceinline__ void decode2_word_bytes_range(const uint64_t* __restrict__ bits, uint64_t lo, uint64_t hi, uint8_t* __restrict__ out, uint64_t w) {
+    const uint64_t i0 = w * 27;
+    const uint64_t word = bits[w];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        uint32_t l = letters5(digits3((uint32_t)(word >> (7 * t)) & 0x7Fu));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (i0 + 3 * t + j >= lo && i0 + 3 * t + j < hi) out[i0 + 3 * t + j] = (uint8_t)(l >> (8 * j));
+    }
+}
+__device__ __forceinline__ void decode2_page_edges(const Decode2PageEdges& e, uint64_t idx, uint64_t stride) {
+    const uint64_t head_words = (e.head_nt + 26) / 27, tail_w0 = e.tail_from / 27, tail_words = e.tail_from < e.len ? (e.len + 26) / 27 - tail_w0 : 0;
+    for (uint64_t i = idx; i < head_words + tail_words; i += stride) {
+        if (i < head_words) decode2_word_bytes_range(e.bits, 0, e.head_nt, e.out, i);
+        else decode2_word_bytes_range(e.bits, e.tail_from, e.len, e.out, tail_w0 + (i - head_words));
+    }
+}
+// `bits` = the call's packed array (8-B aligned), `words` its length; `out` + nt0 is 128-B aligned, nt0 = the first letter
+// of this launch's first page
+template <int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(64) void bits_to_n2_page(const uint64_t* __restrict__ bits, uint64_t words, uint8_t* __restrict__ out, uint64_t nt0,
+                                                       uint32_t n_tiles, uint32_t xs, Decode2PageEdges e) {
+    __shared__ __attribute__((aligned(16))) uint32_t my[kPageSlabDwords5];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
+    const uint64_t l0 = nt0 + t * kPageNt5, w0 = l0 / 27;
+    const uint32_t r = (uint32_t)(l0 - w0 * 27);
+    const uint64_t left = words - w0;  // >= 1: the page lies inside the decoded length
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(bits + w0, (uint32_t)(left < (uint64_t)kPageWords5 ? left : (uint64_t)kPageWords5) * 8);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + l0, kPageNt5);
+    typedef unsigned int vu2 __attribute__((__vector_size__(8)));
+    vu2 w2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
+    const uint32_t byte0 = 27u * lane + 32u - r, q0 = byte0 >> 2, ph = byte0 & 3u;
+    const uint32_t sel = 0x07060504u - 0x01010101u * ph;
+    const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
+    uint32_t carry = 0;  // round 0, lane 0: the bytes in front of word w0 lie in front of the page
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        uint32_t b[7];
+        decode27(w2[j][0], w2[j][1], b);
+        uint32_t W[8];
+        W[0] = __builtin_amdgcn_perm(b[0], 0u, sel);
+#pragma unroll
+        for (int k = 1; k < 7; ++k) W[k] = __builtin_amdgcn_perm(b[k], b[k - 1], sel);
+        W[7] = __builtin_amdgcn_perm(0u, b[6], sel);
+        const uint32_t tail = cnt == 6 ? W[6] : W[7];
+        uint32_t prev_tail = __shfl_up(tail, 1, 64);
+        if (lane == 0) prev_tail = carry;
+        carry = __builtin_amdgcn_readlane(tail, 63);
+        if (ph != 0) W[0] |= prev_tail;
+        uint32_t* dst = my + kWaveDwords5 * j + q0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dst[k] = W[k];
+        if (cnt == 7) dst[6] = W[6];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(my + 8 + (i * 64 + lane) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
+    }
+    if (blockIdx.x + e.groups >= n_tiles)
+        decode2_page_edges(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+}
+
+// ---------------------------------------------------------------------------
 // PIPELINED wave tiles (round 4).  The L2 <-> fabric counters (profiles/r04_bound_counters_codec5.json) show both
 // directions IN-FLIGHT starved, not pushed back by the memory side: the encoder keeps 36.6k reads outstanding at the
 // 2-bit encoder's latency (0.93 us) where that one keeps 39.2k, the decoder 12.8k writes where the 2-bit decoder keeps

@@ -136,8 +136,24 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s, ld=plain st=sc0|sc1|nt, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 47
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-8s, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},   // 48
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-16s, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 49
+    // page tiles: one wave per 4-KiB page of the ASCII (write) stream, bits_to_n2_page
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 12 wg/CU", kPageNt5, 64, 12},  // 50
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 13 wg/CU", kPageNt5, 64, 13},  // 51
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 14 wg/CU", kPageNt5, 64, 14},  // 52
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 11 wg/CU", kPageNt5, 64, 11},  // 53
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 10 wg/CU", kPageNt5, 64, 10},  // 54
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 16 wg/CU", kPageNt5, 64, 16},  // 55
+    {"page-tiled, xcd-quads, ld=plain st=sc0|sc1|nt, 12 wg/CU", kPageNt5, 64, 12},    // 56
+    {"page-tiled, xcd-pairs, ld=plain st=sc0|sc1|nt, 12 wg/CU", kPageNt5, 64, 12},    // 57
+    {"page-tiled, plain order, ld=nt st=sc0|sc1|nt, 12 wg/CU", kPageNt5, 64, 12},     // 58
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 18 wg/CU", kPageNt5, 64, 18},  // 59
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 20 wg/CU", kPageNt5, 64, 20},  // 60
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 24 wg/CU", kPageNt5, 64, 24},  // 61
+    {"page-tiled, plain order, ld=plain st=sc0|sc1|nt, 30 wg/CU", kPageNt5, 64, 30},  // 62
+    {"page-tiled, xcd-quads, ld=plain st=sc0|sc1|nt, 20 wg/CU", kPageNt5, 64, 20},    // 63
 #endif
 };
+constexpr int kFirstPageDecode2Variant = 50;
 #ifdef CNT_LAB_VARIANTS
 inline int decode2_waves(int variant) { return variant == 3 || (variant >= 41 && variant <= 43) ? 4 : variant == 2 || variant == 44 || variant == 45 ? 2 : 1; }
 inline int decode2_pipe_k(int variant) { return variant == 32 || variant == 33 || variant == 39 ? 2 : variant == 37 || variant == 38 ? 8 : (variant >= 34 && variant <= 40) ? 4 : 0; }
@@ -292,5 +308,37 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
     }
     return 0;
 }
+
+#ifdef CNT_LAB_VARIANTS
+// Page-tiled decode of a whole call: letters [0, head_nt) in front of the first 128-B line of d_out and the letters behind
+// the last whole page ride as edge items in the (last) launch.  Returns 1 for an unknown variant, -1 when the call holds no
+// whole page (the caller's generic kernel takes it), 0 after launching.
+inline int launch_decode2_page(int variant, const uint64_t* bits, uint64_t words, uint8_t* out, uint64_t len, hipStream_t s) {
+    if (variant < kFirstPageDecode2Variant || variant >= kNumDecode2Variants) return 1;
+    const uint64_t head_nt = (128 - (reinterpret_cast<uintptr_t>(out) & 127)) & 127;
+    if (len < head_nt + kPageNt5) return -1;
+    const uint64_t total = (len - head_nt) / kPageNt5;
+    Decode2PageEdges e{bits, out, len, head_nt, head_nt + total * kPageNt5, 0};
+    const uint64_t edge_items = (head_nt + 26) / 27 + (e.tail_from < len ? (len + 26) / 27 - e.tail_from / 27 : 0);
+    const uint64_t per_launch = max_tiles_per_launch(64) / 8 * 8;
+    const uint32_t xs = xcd_shift();
+    const uint32_t lds = lds_pad_for_cap(kDecode2Variants[variant].wg_cap, kPageSlabDwords5 * 4);
+    constexpr int kAll = kSC0 | kSC1 | kNT;
+    for (uint64_t first = 0; first < total; first += per_launch) {
+        const uint64_t n = total - first < per_launch ? total - first : per_launch;
+        e.groups = first + n == total ? edge_groups(edge_items, 64, n) : 0u;
+        const uint64_t nt0 = head_nt + first * kPageNt5;
+#define CNT_DEC2PG(C, L) hipLaunchKernelGGL((bits_to_n2_page<C, L, kAll>), dim3(grid_of(n)), dim3(64), lds, s, bits, words, out, nt0, (uint32_t)n, xs, e)
+        switch (variant) {
+            case 56: case 63: CNT_DEC2PG(4, 0); break;
+            case 57: CNT_DEC2PG(2, 0); break;
+            case 58: CNT_DEC2PG(1, kNT); break;
+            default: CNT_DEC2PG(1, 0); break;
+        }
+#undef CNT_DEC2PG
+    }
+    return 0;
+}
+#endif
 
 }  // namespace cnt
