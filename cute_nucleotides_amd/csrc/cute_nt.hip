@@ -59,6 +59,13 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? CNT_OK : -(int)e; }
 #define HIP_TRY(expr) CNT_TRY(hip_rc(expr))
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+// The reference borrows its input and returns a fresh Vec (n_to_bits.rs:34,51): input and output never share memory.  With
+// caller-owned outputs they could; every codec entry point refuses that (CNT_EINVAL) instead of racing its tiles' reads
+// against other tiles' stores.
+inline bool overlaps(const void* a, size_t a_bytes, const void* b, size_t b_bytes) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+    return a_bytes && b_bytes && x < y + b_bytes && y < x + a_bytes;
+}
 
 // ---- tuning knobs: LAB BUILD ONLY -------------------------------------------------------
 // The product library selects nothing at run time: every tune_*() below is a compile-time constant there, the variant

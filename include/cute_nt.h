@@ -20,6 +20,9 @@
  *     <0 = -(hipError_t) from the HIP runtime.  cnt_strerror() names any of them.
  *   - caller-allocated outputs.  The library never keeps a caller pointer after
  *     return and never frees caller memory.
+ *   - inputs and outputs of one call do not share memory (the reference borrows
+ *     `&[u8]` / `&[u64]` and returns a fresh Vec, n_to_bits.rs:34,51): a codec call
+ *     whose input range overlaps one of its output ranges is CNT_EINVAL, in every tier.
  *   - thread-safe and re-entrant: per-thread HIP stream + scratch (the
  *     reference's functions are pure and callable from any thread).
  *   - layout (n_to_bits.rs:39-42,61-64): nucleotide i lives in word i>>5 at bit
@@ -41,7 +44,7 @@ extern "C" {
 
 /* ---- status codes ---------------------------------------------------------- */
 #define CNT_OK 0
-#define CNT_EINVAL 1 /* NULL pointer with a non-zero size, bad flag, bad ndev */
+#define CNT_EINVAL 1 /* NULL pointer with a non-zero size, bad flag, bad ndev, input overlapping output */
 #define CNT_ECAP 2   /* output capacity < ceil(n_len/32) (or /27) words */
 #define CNT_ELEN 3   /* decode: len > 32*words (27*words) -- the reference's
                         panic "The length is greater than the number of

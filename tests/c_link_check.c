@@ -19,6 +19,7 @@ int main(void) {
     if (cnt_n_to_bits(n, 64, out, 1) != CNT_ECAP) return 5;              /* argument errors need no device */
     if (cnt_bits_to_n(out, 1, 33, n) != CNT_ELEN) return 6;
     if (cnt_n_to_bits(NULL, 0, NULL, 0) != CNT_OK) return 7;               /* empty in -> empty out */
+    if (cnt_n_to_bits(n, 32, (uint64_t *)(n + 24), 1) != CNT_EINVAL) return 14;  /* input and output never share memory */
     if (cnt_device_count(&count) != CNT_OK) return 8;
     if (count == 0 && cnt_n_to_bits(n, 64, out, 2) != CNT_ENODEV) return 9;  /* no CPU fallback */
     {   /* the enqueue-only multi-GPU tier from C: no device -> no queue; unknown handles are refused, not dereferenced */

@@ -89,6 +89,28 @@ def test_argument_errors_before_any_device_work(L):
     assert L.cnt_n_to_bits(None, 64, p(out), 2) == _lib.CNT_EINVAL
     # unknown flag
     assert L.cnt_n_to_bits_dev(p(n), 32, p(out), 1, 0x80, None) == _lib.CNT_EINVAL
+    # input and output of one call never share memory (the reference returns a fresh Vec): every tier refuses
+    big = np.zeros(4096, dtype=np.uint8)
+    q = lambda off: ctypes.c_void_p(big.ctypes.data + off)
+    assert L.cnt_n_to_bits(q(0), 64, q(56), 2) == _lib.CNT_EINVAL  # out starts inside n
+    assert L.cnt_n_to_bits(q(8), 64, q(0), 2) == _lib.CNT_EINVAL  # out ends inside n
+    assert L.cnt_n_to_bits_dev(q(0), 64, q(0), 2, 0, None) == _lib.CNT_EINVAL
+    assert L.cnt_n_to_bits2_dev(q(0), 54, q(48), 2, 0, None) == _lib.CNT_EINVAL
+    assert L.cnt_n_to_bits_sharded(q(0), 64, q(0), 2, 1) == _lib.CNT_EINVAL
+    assert L.cnt_bits_to_n(q(0), 2, 64, q(8)) == _lib.CNT_EINVAL
+    assert L.cnt_bits_to_n_dev(q(64), 2, 64, q(8), 0, None) == _lib.CNT_EINVAL  # out's last byte is bits' first
+    assert L.cnt_bits_to_n2_dev(q(0), 2, 54, q(8), 0, None) == _lib.CNT_EINVAL
+    assert L.cnt_bits_to_n_sharded(q(0), 2, 64, q(15), 1) == _lib.CNT_EINVAL
+    assert L.cnt_round_trip_dev(q(0), 64, q(1024), 2, q(32), 0, None) == _lib.CNT_EINVAL  # back inside n
+    assert L.cnt_round_trip_dev(q(0), 64, q(56), 2, q(2048), 0, None) == _lib.CNT_EINVAL  # packed inside n
+    assert L.cnt_round_trip_dev(q(0), 64, q(1024), 2, q(1032), 0, None) == _lib.CNT_EINVAL  # back inside packed
+    # ... adjacent is fine: past the argument checks these need a device (none here: CNT_ENODEV; on a GPU box they would run
+    # on host pointers, so they are only tried without one)
+    count = ctypes.c_int(-1)
+    assert L.cnt_device_count(ctypes.byref(count)) == _lib.CNT_OK
+    if count.value == 0:
+        assert L.cnt_n_to_bits(q(0), 64, q(64), 2) == _lib.CNT_ENODEV
+        assert L.cnt_bits_to_n(q(64), 2, 64, q(0)) == _lib.CNT_ENODEV
     # generator offsets must sit on block boundaries
     assert L.cnt_fill_random_acgt_dev(p(buf), 5, 32, 1, None) == _lib.CNT_ERANGE
     assert L.cnt_fill_random_acgtn_dev(p(buf), 5, 27, 1, None) == _lib.CNT_ERANGE
