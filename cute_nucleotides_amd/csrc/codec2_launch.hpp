@@ -257,6 +257,7 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
 // pieces of the WIDE streams per workgroup.
 constexpr uint32_t kRoundTripTile = 64 * 4 * 16;
 constexpr uint32_t kRoundTripDefaultCap = 8;
+constexpr int kRoundTripDefaultPlan = 3;  // any-alignment launch plan (device_tier.inc round_trip_plan): priced candidates
 // shape 0 = the default above; shape 1 = the first shipped shape (<64, 2, 2>: two loads, XCD pairs; wants cap 13),
 // two of its 2-KiB tiles per 4-KiB unit -- kept selectable (tuning key "round_trip_shape") for A/B runs
 template <bool STRICT>

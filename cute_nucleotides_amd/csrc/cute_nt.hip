@@ -97,6 +97,8 @@ inline int tune_round_trip_shape() { return g_round_trip_shape.load(std::memory_
 inline uint32_t tune_round_trip_cap() { return (uint32_t)g_round_trip_cap.load(std::memory_order_relaxed); }
 std::atomic<int> g_round_trip_window_map{0};  // tile map of the any-alignment fused kernel: 0 plain order (shipped), 1 XCD pairs, 2 XCD quads
 inline int tune_round_trip_window_map() { return g_round_trip_window_map.load(std::memory_order_relaxed); }
+std::atomic<int> g_round_trip_plan{kRoundTripDefaultPlan};  // pricing of the any-alignment fused launch plan (device_tier.inc round_trip_plan): 3 = shipped; 0 tiles on d_back's pages, 1 windows on d_n's pages, 2 shortest read-ahead
+inline int tune_round_trip_plan() { return g_round_trip_plan.load(std::memory_order_relaxed); }
 #else
 constexpr int tune_encode() { return 0; }
 constexpr int tune_decode() { return 0; }
@@ -106,6 +108,7 @@ constexpr size_t tune_small_nt() { return (size_t)1 << 17; }
 constexpr int tune_round_trip_shape() { return 0; }
 constexpr uint32_t tune_round_trip_cap() { return kRoundTripDefaultCap; }
 constexpr int tune_round_trip_window_map() { return 0; }
+constexpr int tune_round_trip_plan() { return kRoundTripDefaultPlan; }
 #endif
 
 inline unsigned generic_grid(uint64_t items) {
@@ -432,6 +435,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_window_map")) {
         if (value < 0 || value > 2) return CNT_EINVAL;
         g_round_trip_window_map.store(value);
+    } else if (!strcmp(key, "round_trip_plan")) {
+        if (value < 0 || value > 3) return CNT_EINVAL;
+        g_round_trip_plan.store(value);
     } else if (!strcmp(key, "reduce_persistent")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_persistent.store(value);
@@ -548,7 +554,7 @@ int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uin
     const uint64_t lut_from = lut_from_of(n_len, flags, 32);
     const uint64_t limit = lut_from != kNoLutWord && !strict ? n_len & ~(uint64_t)31 : n_len;
     const bool fast = !(a_n & 127) && !(a_bits & 127) && !(a_back & 127) && n_len >= kRoundTripTile;
-    const RoundTripPlan p = fast ? RoundTripPlan{} : round_trip_plan((uintptr_t)a_n, (uintptr_t)a_bits, (uintptr_t)a_back, n_len, limit);
+    const RoundTripPlan p = fast ? RoundTripPlan{} : round_trip_plan((uintptr_t)a_n, (uintptr_t)a_bits, (uintptr_t)a_back, n_len, limit, tune_round_trip_plan());
     out[0] = fast ? 1 : 0;  // 1: the aligned kernel (round_trip_stream) takes the call
     out[1] = p.t0;
     out[2] = p.p0;

@@ -38,12 +38,13 @@ def _check(L, a_n, a_bits, a_back, n_len, flags):
         return 0
     if tiles == 0:
         return 0
-    grain = 4096 if n_len >= (1 << 20) else 128
     t1, p1 = t0 + TILE * tiles, p0 + (TILE // 16) * tiles
     words = (n_len + 31) // 32
     dwords = 2 * words
     # stores: decoded stream on its grain, packed stream on a 64-B segment
-    assert (a_back + t0) % grain == 0 and (a_bits + 4 * p0) % 64 == 0, where
+    assert (a_back + t0) % 128 == 0 and (a_bits + 4 * p0) % 64 == 0, where
+    # the head left to the edge items: under two pages (large buffers: the plan looks that far for a cheap start), one line otherwise
+    assert t0 < (8192 + 128 if n_len >= (1 << 20) else 256 + 128), where
     # window: 128-B aligned, starts inside the buffer, holds both first nucleotides
     assert w0 >= 0 and (a_n + w0) % 128 == 0 and phase == t0 - w0 and phase2 == 16 * p0 - w0, where
     assert 0 <= phase <= 127 + 143 and 0 <= phase2 <= 127 + 143, where
@@ -91,8 +92,10 @@ def test_lengths_sweep_a_whole_period_for_sampled_phases(L):
             _check(L, a_n, a_bits, a_back, n_len, 0)
 
 
-def test_large_buffers_lay_tiles_on_4k_pages(L):
-    """n >= 2^20: the decoded stream's grain is a 4-KiB page; sampled output phases mod 4096 x all input phases x packed phases"""
+def test_large_buffers_price_two_pages_of_starts(L):
+    """n >= 2^20: every start on a line of d_back within two pages x both segment choices is priced (read-ahead lines, window on
+    a page of d_n); sampled output phases mod 4096 x input phases x packed phases.  Whenever SOME start reads one line ahead from a
+    page-aligned window, the plan's does."""
     import random
 
     rnd = random.Random(5)
@@ -100,6 +103,15 @@ def test_large_buffers_lay_tiles_on_4k_pages(L):
         a_n, a_bits, a_back = 0x7D0000000000 + rnd.randrange(4096), 0x7D1000000000 + 8 * rnd.randrange(16), 0x7D2000000000 + rnd.randrange(4096)
         n_len = (1 << 20) + rnd.randrange(1 << 16)
         assert _check(L, a_n, a_bits, a_back, n_len, rnd.choice((0, CNT_TAIL_LUT, CNT_STRICT_LUT))) or (a_n % 128 == 0 and a_bits % 128 == 0 and a_back % 128 == 0)
+        fast, t0, p0, tiles, w0, phase, phase2, _ = _plan(L, a_n, a_bits, a_back, n_len, 0)
+        if fast:
+            continue
+        # the cheapest kind of start exists iff phi = (d_n - d_back) mod 128 and psi = the packed stream's offset from a page-aligned
+        # window (mod 256) both leave the read-ahead inside one line: (max >> 4) + 2 <= 8 vectors
+        phi = (a_n - a_back) % 128
+        psi = (16 * ((-a_bits) % 64 // 4) + a_n) % 256
+        if max(phi, psi) < 112:
+            assert (a_n + w0) % 4096 == 0 and max(phase, phase2) < 112, (a_n, a_bits, a_back, n_len, phase, phase2, phi, psi)
 
 
 def test_tiny_and_degenerate_inputs(L):
