@@ -432,7 +432,7 @@ __device__ __forceinline__ void round_trip_edges_any(const RoundTripEdgesAny& e,
     }
 }
 constexpr uint32_t kRoundTripAnyTile = 64 * 4 * 16;
-constexpr uint32_t kRoundTripAnySlackVecs = 25;  // 16-B vectors of the window a tile may read behind its 4 KiB (the launcher needs <= 17)
+constexpr uint32_t kRoundTripAnySlackVecs = 25;  // 16-B vectors of the window a tile may read behind its 4 KiB (the launcher needs <= 24: phases < 128 + 256)
 constexpr uint32_t kRoundTripAnySlack = kRoundTripAnySlackVecs * 16;  // bytes a tile's window may read behind the tile's own end
 constexpr uint32_t kRoundTripAnySlab = 5 * 64 * 4;  // LDS bytes: four rows of code dwords + the slack row
 template <int C, int LAUX, int SAUX, bool STRICT>
@@ -449,9 +449,10 @@ __global__ __launch_bounds__(kWave) void round_trip_window(const uint8_t* __rest
     u32x4 v[5];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * kWave + lane) * 16, 0, LAUX));
-    // lanes 0..max(q, q2)+1 fetch the vectors behind the tile that the two funnels reach; the others aim past the
-    // descriptor's range (zeros, no memory access)
-    v[4] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane <= max(q, q2) + 1 ? (4 * kWave + lane) * 16 : 0xFFFFFF00u, 0, LAUX));
+    // the two funnels reach code dword 255 + q + 1 (+ q2), and only with a bit phase: ceil(max(phase, phase2) / 16) vectors
+    // behind the tile's own 256, fetched by that many lanes; the others aim past the descriptor's range (zeros, no memory
+    // access).  A phase of up to 128 letters is ONE further line.
+    v[4] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane < ((max(phase, phase2) + 15u) >> 4) ? (4 * kWave + lane) * 16 : 0xFFFFFF00u, 0, LAUX));
 #pragma unroll
     for (int u = 0; u < 5; ++u) residency_pad[u * kWave + lane] = enc16<STRICT>(v[u]);
     wave_lds_fence();

@@ -47,10 +47,11 @@ def _check(L, a_n, a_bits, a_back, n_len, flags):
     assert t0 < (8192 + 128 if n_len >= (1 << 20) else 256 + 128), where
     # window: 128-B aligned, starts inside the buffer, holds both first nucleotides
     assert w0 >= 0 and (a_n + w0) % 128 == 0 and phase == t0 - w0 and phase2 == 16 * p0 - w0, where
-    assert 0 <= phase <= 127 + 143 and 0 <= phase2 <= 127 + 143, where
+    assert 0 <= phase < 128 + 256 and 0 <= phase2 < 128 + 256, where
     q, q2 = phase >> 4, phase2 >> 4
-    # the fifth load's lanes 0..max(q, q2)+1 fetch vectors 256..: inside the descriptor's slack and inside the slab (5 rows of 64)
-    extra = max(q, q2) + 2
+    # the fifth load's lanes 0..ceil(max(phase, phase2) / 16)-1 fetch vectors 256..: inside the descriptor's slack; the funnels'
+    # highest slab index 255 + max(q, q2) + 1 inside the slab (5 rows of 64)
+    extra = (max(phase, phase2) + 15) >> 4
     assert extra <= slack_vecs and extra <= 64 and 255 + max(q, q2) + 1 < 320, where
     # the last tile's window ends inside the buffer (its highest vector is loaded whole)
     assert w0 + TILE * tiles + 16 * extra <= n_len, where
@@ -107,11 +108,11 @@ def test_large_buffers_price_two_pages_of_starts(L):
         if fast:
             continue
         # the cheapest kind of start exists iff phi = (d_n - d_back) mod 128 and psi = the packed stream's offset from a page-aligned
-        # window (mod 256) both leave the read-ahead inside one line: (max >> 4) + 2 <= 8 vectors
+        # window (mod 256) both leave the read-ahead inside one line: ceil(max / 16) <= 8 vectors
         phi = (a_n - a_back) % 128
         psi = (16 * ((-a_bits) % 64 // 4) + a_n) % 256
-        if max(phi, psi) < 112:
-            assert (a_n + w0) % 4096 == 0 and max(phase, phase2) < 112, (a_n, a_bits, a_back, n_len, phase, phase2, phi, psi)
+        if max(phi, psi) <= 128:
+            assert ((a_n + w0) % 4096 == 0 and max(phase, phase2) <= 128) or max(phase, phase2) == 0, (a_n, a_bits, a_back, n_len, phase, phase2, phi, psi)
 
 
 def test_tiny_and_degenerate_inputs(L):
