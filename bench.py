@@ -382,6 +382,15 @@ def main():
         if verified is not None:  # the fused kernel's own outputs: same packed words, same decoded text
             fused["verified"] = devutil.count_mismatch(d_in, d_out) == 0 and devutil.checksum_words(d_packed) == packed_sum
             verified = verified and fused["verified"]
+        if n_len >= (1 << 22):  # the same call with all three pointers off the 128-B grid: one launch as well (round_trip_window)
+            m = n_len - 4096
+            v_in, v_pk, v_out = d_in[5 : 5 + m], d_packed[1 : 1 + (m + 31) // 32], d_out[77 : 77 + m]
+            fused["off_grid"] = stats_ms(timed_calls(torch, lambda: cn.round_trip_dev(v_in, out_bits=v_pk, out_n=v_out), 5))
+            fused["off_grid"]["nt"] = m
+            if verified is not None:
+                k = min(m, 1 << 28)
+                fused["off_grid"]["verified"] = bool(torch.equal(v_out[:k], v_in[:k]) and torch.equal(v_out[-k:], v_in[-k:]))
+                verified = verified and fused["off_grid"]["verified"]
 
     # ---- BASELINE.json configs[1] / [2]: 1 GiB, and a ragged size, on the first 2^30 nt of the same buffers (bench_measure.py) ----
     configs = measure_configs_1gib(torch, d_in, d_packed, d_out, verified is not None) if extras and n_len >= (1 << 30) else {}
@@ -549,6 +558,10 @@ def main():
                 "ms": fused["median"], "ms_stats": fused, "nt_converted_gnts": round(2 * n_len / (fused["median"] * 1e-3) / 1e9, 3),
                 "bytes_per_nt": 2.25, "achieved": round(fgbs, 1), "unit": "GB/s", "frac": round(fgbs / HBM_PEAK_GBS, 4),
             }
+            if "off_grid" in fused:  # d_n + 5 B, d_bits + 8 B, d_back + 77 B: still one launch
+                og = fused["off_grid"]
+                line["fused_round_trip"]["off_grid_frac"] = round(gbs(2.25 * og["nt"], og["median"]) / HBM_PEAK_GBS, 4)
+                line["fused_round_trip"]["off_grid_vs_aligned"] = round((og["median"] / og["nt"]) / (fused["median"] / n_len), 4)
         if ceilings is not None:
             line["ceilings"] = {
                 "what": "no-arithmetic streams issued exactly like the shipped kernels (bench/probes.hip probe_shipped), same process, "

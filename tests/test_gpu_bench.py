@@ -48,6 +48,9 @@ def test_single_gpu_line_small():
     assert c1["frac"] > 0.3 and c1["timing"].startswith("10 launches queued") and c1["isolated_single_launch"]["frac"] > 0.3
     assert j["configs"]["configs[2] bits_to_n decode, 1 GiB (2^30 nt)"]["round_trip_verified"] is True
     assert j["fused_round_trip"]["ms_stats"]["verified"] is True
+    # ... and the same call with all three pointers off the 128-B grid, one launch too: within 10 % of the aligned one at 2^30 nt
+    og = j["fused_round_trip"]["ms_stats"]["off_grid"]
+    assert og["verified"] is True and og["nt"] == (1 << 30) - 4096 and 0.9 < j["fused_round_trip"]["off_grid_vs_aligned"] < 1.1
     rag = j["configs"]["ragged: 2^30 - 19 nt (13 nt in the last word, zero-padded)"]
     assert rag["round_trip_verified"] is True and rag["encode_frac"] > 0.3 and rag["decode_frac"] > 0.3
     # the ragged size is ONE launch per call now: within a few percent of the aligned size in the same run
