@@ -587,6 +587,12 @@ def main():
                     "of_copy_1to1_ceiling": round(dec_gbs / c["copy_1to1"]["GBs"], 4),
                     "of_write_only_ceiling": round(dec_gbs / c["write_only"]["GBs"], 4),
                 }
+                if fused is not None:  # 1 B read : 1.25 B written per nt -- the nearest arithmetic-free stream is the 1:1 copy
+                    line["ceilings"]["fused_vs"] = {
+                        "total_traffic_view_GBs": round(fgbs, 1),
+                        "of_spec_8000": round(fgbs / HBM_PEAK_GBS, 4),
+                        "of_copy_1to1_ceiling": round(fgbs / c["copy_1to1"]["GBs"], 4),
+                    }
         if configs:
             line["configs"] = configs
         if codec5 is not None:

@@ -27,7 +27,9 @@ rows = [
      "%.3f of the read-only probe" % ev["read_only_view_of_read_only_ceiling"]),
     ("`bits_to_n` (mean %.3f ms; median %.3f, min %.3f)" % (d["kernel_ms"]["mean"], d["kernel_ms"]["median"], d["kernel_ms"]["min"]), tb(d["achieved"]), "**%.3f**" % d["frac"],
      "%.3f" % dv["of_read1_write4_ceiling"]),
-    ("fused round trip, 2^34 / 2^36 nt", "%s / %s" % (tb(f["achieved"]), tb(k3f.get("achieved_GBs", 0))), "%.3f / %.3f" % (f["frac"], k3f.get("frac", 0)), "—"),
+    ("fused round trip, 2^34 / 2^36 nt" + ("; all three pointers off the 128-B grid, 2^34" if "off_grid_frac" in f else ""),
+     "%s / %s" % (tb(f["achieved"]), tb(k3f.get("achieved_GBs", 0))), "%.3f / %.3f" % (f["frac"], k3f.get("frac", 0)) + ("; %.3f" % f["off_grid_frac"] if "off_grid_frac" in f else ""),
+     "%.3f of the 1 : 1 copy" % j["ceilings"]["fused_vs"]["of_copy_1to1_ceiling"] if "fused_vs" in j["ceilings"] else "—"),
     ("`configs[1]` / `[2]`: 1 GiB encode / decode", "%s / %s" % (tb(k1["achieved_GBs"]), tb(k2["achieved_GBs"])), "%.3f / %.3f" % (k1["frac"], k2["frac"]),
      "(0.2 ms launches; the 256 MiB of words sit in the Infinity Cache)"),
     ("`configs[3]`: 64 GiB, two passes", tb(k3.get("achieved_GBs", 0)), "%.3f" % k3.get("frac", 0), "—"),

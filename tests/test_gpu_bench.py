@@ -43,6 +43,8 @@ def test_single_gpu_line_small():
     ev = j["ceilings"]["encode_vs"]
     assert abs(ev["of_spec_8000"] - j["roofline"]["frac"]) < 1e-3 and 0.5 < ev["of_read4_write1_ceiling"] < 1.3
     assert abs(ev["read_only_view_of_spec_8000"] - j["roofline"]["read_only_view"]["frac"]) < 1e-3
+    fv = j["ceilings"]["fused_vs"]  # the fused kernel against the arithmetic-free 1:1 copy of the same run
+    assert abs(fv["of_spec_8000"] - j["fused_round_trip"]["frac"]) < 1e-3 and 0.6 < fv["of_copy_1to1_ceiling"] < 1.3
     # the 1 GiB configs, measured on the same buffers; the fused pass verified against the two-pass outputs
     c1 = j["configs"]["configs[1] n_to_bits encode, 1 GiB (2^30 nt)"]
     assert c1["frac"] > 0.3 and c1["timing"].startswith("10 launches queued") and c1["isolated_single_launch"]["frac"] > 0.3
