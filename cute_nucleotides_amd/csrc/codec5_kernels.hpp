@@ -440,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
 
 // ---------------------------------------------------------------------------
 // PAGE tiles for the decoder (round 4).  The word tiles above give every wave 3456 B = 27 lines of the ASCII stream, so
-// each 4-KiB page of the stream that carries 77 % of the bytes is written by two waves; bench/codec5_page_lab.hip prices
+// each 4-KiB page of the stream that carries 77 % of the bytes is written by two waves; an arithmetic-free lab (profiles/r04_codec5_page_tiles_probe.jsonl) prices
 // the two address patterns without arithmetic: one wave per whole page of the WRITE stream (four full 1-KiB stores -- the
 // 2-bit decoder's shape) and a ragged 1213.6-B piece of the packed stream runs 3 % faster than the word tiles.  Here
 // tile t owns letters [4096 t, 4096 t + 4096) of the launch: its first word is w0 = 4096 t / 27, the page starts r =
