@@ -451,7 +451,13 @@ __global__ __launch_bounds__(WAVES * 64) void bits_to_n2_wave(const uint8_t* __r
 // through one v_readlane.  Words past the end of the packed array read as 0 through the descriptor; their letters lie
 // behind the page.
 // ---------------------------------------------------------------------------
-constexpr int kPageNt5 = 4096, kPageWords5 = 153, kPageSlabDwords5 = (32 + 27 * 192 + 3) / 4 + 4;
+constexpr int kPageNt5 = 4096;
+// PAGES consecutive pages per wave: 153 words in 3 rounds of 64 lanes (the third keeps 25 busy) or 305 in 5 (49 in the fifth)
+template <int PAGES> struct PageTile5 {
+    static_assert(PAGES == 1 || PAGES == 2, "one or two pages per wave");
+    static constexpr int kNt = PAGES * kPageNt5, kWords = (26 + kNt + 26) / 27, kRounds = (kWords + 63) / 64;
+    static constexpr int kSlabDwords = (32 + 27 * 64 * kRounds + 3) / 4 + 4;
+};
 struct Decode2PageEdges {
     const uint64_t* bits;
     uint8_t* out;
@@ -479,27 +485,28 @@ __device__ __forceinline__ void decode2_page_edges(const Decode2PageEdges& e, ui
 }
 // `bits` = the call's packed array (8-B aligned), `words` its length; `out` + nt0 is 128-B aligned, nt0 = the first letter
 // of this launch's first page
-template <int C, int LAUX, int SAUX>
+template <int C, int LAUX, int SAUX, int PAGES = 1>
 __global__ __launch_bounds__(64) void bits_to_n2_page(const uint64_t* __restrict__ bits, uint64_t words, uint8_t* __restrict__ out, uint64_t nt0,
                                                        uint32_t n_tiles, uint32_t xs, Decode2PageEdges e) {
-    __shared__ __attribute__((aligned(16))) uint32_t my[kPageSlabDwords5];
+    using T = PageTile5<PAGES>;
+    __shared__ __attribute__((aligned(16))) uint32_t my[T::kSlabDwords];
     const uint32_t lane = threadIdx.x;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
-    const uint64_t l0 = nt0 + t * kPageNt5, w0 = l0 / 27;
+    const uint64_t l0 = nt0 + t * T::kNt, w0 = l0 / 27;
     const uint32_t r = (uint32_t)(l0 - w0 * 27);
     const uint64_t left = words - w0;  // >= 1: the page lies inside the decoded length
-    const __amdgpu_buffer_rsrc_t rin = rsrc_of(bits + w0, (uint32_t)(left < (uint64_t)kPageWords5 ? left : (uint64_t)kPageWords5) * 8);
-    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + l0, kPageNt5);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(bits + w0, (uint32_t)(left < (uint64_t)T::kWords ? left : (uint64_t)T::kWords) * 8);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + l0, T::kNt);
     typedef unsigned int vu2 __attribute__((__vector_size__(8)));
-    vu2 w2[3];
+    vu2 w2[T::kRounds];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
+    for (int j = 0; j < T::kRounds; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (j * 64 + lane) * 8, 0, LAUX);
     const uint32_t byte0 = 27u * lane + 32u - r, q0 = byte0 >> 2, ph = byte0 & 3u;
     const uint32_t sel = 0x07060504u - 0x01010101u * ph;
     const uint32_t cnt = ((byte0 + 27u) >> 2) - q0;  // 6 or 7
     uint32_t carry = 0;  // round 0, lane 0: the bytes in front of word w0 lie in front of the page
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < T::kRounds; ++j) {
         uint32_t b[7];
         decode27(w2[j][0], w2[j][1], b);
         uint32_t W[8];
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(64) void bits_to_n2_page(const uint64_t* __restrict
     }
     wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * PAGES; ++i) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(my + 8 + (i * 64 + lane) * 4);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, (i * 64 + lane) * 16, 0, SAUX);
     }
