@@ -22,6 +22,8 @@ _cnt_lib.use_lab_build()  # this script selects kernel variants: bench/libcute_n
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-words", type=int, default=29, help="packed words = 2^k (nt = 27 * 2^k; 29 -> 13.5 GiB of ASCII)")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--encode2", default="", help="comma list: only these encode variants, in interleaved rounds")
+ap.add_argument("--decode2", default="", help="comma list: only these decode variants, in interleaved rounds")
 a = ap.parse_args()
 words = 1 << a.log2_words
 n = 27 * words
@@ -51,6 +53,25 @@ def timed(fn):
 bpn = 1.0 + 8.0 / 27.0
 rows = []
 for key, fn in (("encode2", lambda: cn.n_to_bits2_dev(d, out=packed)), ("decode2", lambda: cn.bits_to_n2_dev(packed, n, out=back))):
+    only = [int(x) for x in getattr(a, key).split(",") if x]
+    if only:  # interleaved: one launch of every chosen variant per round, median over the rounds
+        names = dict(devutil.variants(key))
+        ms = {v: [] for v in only}
+        for rnd in range(a.iters + 1):
+            for v in only:
+                devutil.set_tuning(key, v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                if rnd:
+                    ms[v].append(e0.elapsed_time(e1))
+        for v in only:
+            m = sorted(ms[v])[len(ms[v]) // 2]
+            rows.append({"what": key, "variant": v, "kernel": names[v], "ms": round(m, 4), "min_ms": round(min(ms[v]), 4), "frac_of_8TBs": round(bpn * n / m / 1e6 / 8000, 4)})
+        devutil.set_tuning(key, 0)
+        continue
     for v, name in devutil.variants(key):
         devutil.set_tuning(key, v)
         fn()

@@ -15,7 +15,7 @@ import cute_nucleotides_amd as cn  # noqa: E402
 from cute_nucleotides_amd import _lib, devutil  # noqa: E402
 
 _lib.use_lab_build()
-variants = [0] + [v for v, _ in devutil.variants("decode2") if v >= 50]
+variants = [0] + [v for v, _ in devutil.variants("decode2") if v >= (70 if "--k1" in sys.argv else 50)]
 names = dict(devutil.variants("decode2"))
 
 # parity against the shipped kernel (itself checked against the oracle by tests/test_gpu_codec5.py)

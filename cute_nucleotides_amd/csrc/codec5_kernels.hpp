@@ -343,26 +343,28 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 // aligned window that covers its tile (216 + 8 vectors) in its slab, and since every lane
 // already picks its 27 bytes out of the slab at an arbitrary byte position, the phase is just an
 // offset into it.  Reads up to 127 B before and 128 B behind the tile (launcher's business).
+constexpr int kWindowSlabDwords5 = 4 * 64 * 4 + 4;
 template <int LAUX, int SAUX, bool STRICT, int C>
 __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                         uint64_t n_wave_tiles, uint32_t phase, uint32_t xs, Encode2Edges e) {
     constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, WIN_VECS = kWaveVecs5 * WPL + 8;
-    __shared__ __attribute__((aligned(16))) uint32_t my[WIN_VECS * 4 + 4];
+    constexpr int NLD = (WIN_VECS + 63) / 64;
+    // Branch-free on purpose: the fourth 16-B access -- 32 lanes' worth -- is issued by ALL lanes against a descriptor that
+    // ends with the window (lanes 32..63 fall outside: zeros, no memory access), and the slab holds four whole wave rows so
+    // that the LDS side needs no lane mask either.  With lane-masked accesses the compiler split the wave into two exec
+    // branches and issued the fourth load only after lanes 32..63 had WAITED for the first three (two dependent trips to
+    // memory per tile: 4.0 ms against the aligned kernel's 3.4 at 2^34 nt, profiles/r04_align_two_pass.jsonl).
+    __shared__ __attribute__((aligned(16))) uint32_t my[kWindowSlabDwords5];
+    static_assert(NLD * 64 * 4 + 4 == kWindowSlabDwords5, "four wave rows + the read-ahead of the last lane");
     const uint32_t lane = threadIdx.x;
     const uint64_t t = tile_of_block<C>(blockIdx.x, (uint32_t)n_wave_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_BYTES, WIN_VECS * 16);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * (TILE_WORDS * 8), TILE_WORDS * 8);
-    constexpr int NLD = (WIN_VECS + 63) / 64;
     u32x4 v[NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        v[i] = u32x4{0, 0, 0, 0};
-        if ((i + 1) * 64 <= WIN_VECS || lane < (uint32_t)(WIN_VECS - i * 64))
-            v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
-    }
+    for (int i = 0; i < NLD; ++i) v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (i * 64 + lane) * 16, 0, LAUX));
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-        if ((i + 1) * 64 <= WIN_VECS || lane < (uint32_t)(WIN_VECS - i * 64)) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
+    for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(my + (i * 64 + lane) * 4) = v[i];
     wave_lds_fence();
     typedef unsigned int vu2 __attribute__((__vector_size__(8)));
 #pragma unroll

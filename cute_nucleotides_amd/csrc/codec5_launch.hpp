@@ -68,11 +68,16 @@ constexpr VariantDesc kEncode2Variants[] = {
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-32s, ld=nt st=sc1, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 45
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-quads, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 46: 4 KiB of packed OUTPUT per turn
     {"wave-tiled 2 words/lane, 1 wave/wg, xcd-8s, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},    // 47
+    // branch-free twin of variant 0 (the pipelined kernel with K = 1: all four loads and LDS writes without a lane mask)
+    {"branch-free K=1, ld=nt st=sc1, 15 wg/CU", 2 * kWaveBytes5, 64, 15},  // 48
+    {"branch-free K=1, ld=nt st=sc1, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 49
+    {"branch-free K=1, ld=nt st=sc1, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 50
+    {"branch-free K=1, ld=nt st=sc1, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 51
 #endif
 };
 #ifdef CNT_LAB_VARIANTS
 inline int encode2_waves(int variant) { return variant == 3 || (variant >= 38 && variant <= 40) ? 4 : variant == 2 || variant == 41 || variant == 42 ? 2 : 1; }
-inline int encode2_pipe_k(int variant) { return variant == 28 || variant == 29 || variant == 30 || variant == 36 ? 2 : variant == 34 || variant == 35 ? 8 : (variant >= 31 && variant <= 37) ? 4 : 0; }
+inline int encode2_pipe_k(int variant) { return variant >= 48 && variant <= 51 ? 1 : variant == 28 || variant == 29 || variant == 30 || variant == 36 ? 2 : variant == 34 || variant == 35 ? 8 : (variant >= 31 && variant <= 37) ? 4 : 0; }
 #else
 constexpr int encode2_waves(int) { return 1; }
 constexpr int encode2_pipe_k(int) { return 0; }
@@ -158,12 +163,16 @@ constexpr VariantDesc kDecode2Variants[] = {
     {"2-page-tiled, plain order, ld=plain st=sc0|sc1|nt, 9 wg/CU", 2 * kPageNt5, 64, 9},    // 67
     {"2-page-tiled, plain order, ld=plain st=sc0|sc1|nt, 10 wg/CU", 2 * kPageNt5, 64, 10},  // 68
     {"2-page-tiled, plain order, ld=plain st=sc0|sc1|nt, 12 wg/CU", 2 * kPageNt5, 64, 12},  // 69
+    // branch-free twin of the word-tiled kernel (the pipelined kernel with K = 1; plain order)
+    {"branch-free K=1, ld=plain st=sc0|sc1|nt, 16 wg/CU", 2 * kWaveBytes5, 64, 16},  // 70
+    {"branch-free K=1, ld=plain st=sc0|sc1|nt, 14 wg/CU", 2 * kWaveBytes5, 64, 14},  // 71
+    {"branch-free K=1, ld=plain st=sc0|sc1|nt, 18 wg/CU", 2 * kWaveBytes5, 64, 18},  // 72
 #endif
 };
-constexpr int kFirstPageDecode2Variant = 50;
+constexpr int kFirstPageDecode2Variant = 50, kEndPageDecode2Variant = 70;
 #ifdef CNT_LAB_VARIANTS
 inline int decode2_waves(int variant) { return variant == 3 || (variant >= 41 && variant <= 43) ? 4 : variant == 2 || variant == 44 || variant == 45 ? 2 : 1; }
-inline int decode2_pipe_k(int variant) { return variant == 32 || variant == 33 || variant == 39 ? 2 : variant == 37 || variant == 38 ? 8 : (variant >= 34 && variant <= 40) ? 4 : 0; }
+inline int decode2_pipe_k(int variant) { return variant >= 70 && variant <= 72 ? 1 : variant == 32 || variant == 33 || variant == 39 ? 2 : variant == 37 || variant == 38 ? 8 : (variant >= 34 && variant <= 40) ? 4 : 0; }
 #endif
 constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Variants[0]);
 
@@ -198,7 +207,8 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
         if (pk) {
             e.groups = first + n == total ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n / pk) : 0u;
             const uint32_t lds = lds_pad_for_cap(kEncode2Variants[variant].wg_cap, 4608u);  // the pipelined slab is a full 4 KiB (+16 B)
-            if (variant == 37) CNT_ENC2P(4, kNT, kSC0 | kSC1 | kNT);
+            if (pk == 1) CNT_ENC2P(1, kNT, kSC1);
+            else if (variant == 37) CNT_ENC2P(4, kNT, kSC0 | kSC1 | kNT);
             else if (pk == 2) CNT_ENC2P(2, kNT, kSC1);
             else if (pk == 4) CNT_ENC2P(4, kNT, kSC1);
             else CNT_ENC2P(8, kNT, kSC1);
@@ -243,7 +253,7 @@ template <bool STRICT>
 void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, Encode2Edges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
     const uint32_t xs = xcd_shift();
-    const uint32_t lds = lds_pad_for_cap(kEncode2Variants[0].wg_cap, 3584u + 128u);  // the window slab is 128 B larger than variant 0's
+    const uint32_t lds = lds_pad_for_cap(kEncode2Variants[0].wg_cap, kWindowSlabDwords5 * 4u);  // four whole wave rows: 640 B more than variant 0's
     e.tail_first = e.head_words + total_tiles * (kWindowEncode2Tile / 27);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n = total_tiles - first < per_launch ? total_tiles - first : per_launch;
@@ -280,7 +290,8 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
         if (pk) {
             e.groups = first + n == total ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n / pk) : 0u;
             const uint32_t lds = lds_pad_for_cap(kDecode2Variants[variant].wg_cap, 4608u);
-            if (pk == 2) CNT_DEC2P(2);
+            if (pk == 1) CNT_DEC2P(1);
+            else if (pk == 2) CNT_DEC2P(2);
             else if (pk == 4) CNT_DEC2P(4);
             else CNT_DEC2P(8);
             continue;
@@ -321,7 +332,7 @@ inline int launch_decode2(int variant, const void* d_bits, void* d_out, uint64_t
 // the last whole page ride as edge items in the (last) launch.  Returns 1 for an unknown variant, -1 when the call holds no
 // whole page (the caller's generic kernel takes it), 0 after launching.
 inline int launch_decode2_page(int variant, const uint64_t* bits, uint64_t words, uint8_t* out, uint64_t len, hipStream_t s) {
-    if (variant < kFirstPageDecode2Variant || variant >= kNumDecode2Variants) return 1;
+    if (variant < kFirstPageDecode2Variant || variant >= kEndPageDecode2Variant) return 1;
     const uint64_t tile_nt = kDecode2Variants[variant].tile_nt;
     const uint64_t head_nt = (128 - (reinterpret_cast<uintptr_t>(out) & 127)) & 127;
     if (len < head_nt + tile_nt) return -1;
