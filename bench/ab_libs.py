@@ -49,6 +49,7 @@ def load(path):
     L.cnt_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.cnt_hamming_dev.argtypes = [_vp, _vp, _sz, _vp, _vp]
     L.cnt_complement_dev.argtypes = [_vp, _sz, _vp, _vp]
+    L.cnt_reverse_complement_dev.argtypes = [_vp, _sz, _vp, _vp]
     L.cnt_validate_dev.argtypes = [_vp, _sz, _u, _vp, _vp]
     return L
 
@@ -79,7 +80,9 @@ if a.packed_ops:
     for name, L in libs:  # these rows must not run interleaved with encode / decode rows of the same buffers: use --packed-ops alone
         rows.append((name, "hamming", lambda L=L: L.cnt_hamming_dev(d_pk.data_ptr(), d_pk2.data_ptr(), n_len, d_acc.data_ptr(), stream)))
         rows.append((name, "validate", lambda L=L: L.cnt_validate_dev(d_in.data_ptr(), n_len, 0, d_acc.data_ptr() + 8, stream)))
-    rows = [r for r in rows if r[1] in ("hamming", "validate")]
+        rows.append((name, "complement", lambda L=L: L.cnt_complement_dev(d_pk.data_ptr(), n_len, d_out.data_ptr(), stream)))
+        rows.append((name, "reverse_complement", lambda L=L: L.cnt_reverse_complement_dev(d_pk.data_ptr(), n_len, d_out.data_ptr(), stream)))
+    rows = [r for r in rows if r[1] in ("hamming", "validate", "complement", "reverse_complement")]
 L0 = libs[0][1]
 for key, spec in (("decode", a.decode_variants), ("encode", a.encode_variants)):
     for v in [int(x) for x in spec.split(",") if x]:

@@ -318,11 +318,10 @@ __global__ __launch_bounds__(BLOCK) void reverse_complement_tiles(const uint8_t*
     const uint64_t wm = ((uint64_t)q.y << 32) | q.x;   // input word j-1
     const uint64_t wj = ((uint64_t)q.w << 32) | q.z;   // input word j
     const uint64_t wp = ((uint64_t)e[1] << 32) | e[0];  // input word j+1 (0 when sh == 0)
-    uint64_t win0 = wj >> sh, win1 = wm >> sh;
-    if (sh) {
-        win0 |= wp << (64 - sh);
-        win1 |= wj << (64 - sh);
-    }
+    // branch-free: (x << 1) << (63 - sh) is x << (64 - sh) for sh = 2..62 and 0 for sh = 0.  With `if (sh)` around the two ORs
+    // the compiler sank the second load into the branch, BEHIND the first load's s_waitcnt: two dependent trips to memory per
+    // tile whenever len is not a multiple of 32 (tests/test_isa_digest.py now counts the loads in flight at the first wait).
+    const uint64_t win0 = (wj >> sh) | ((wp << 1) << (63 - sh)), win1 = (wm >> sh) | ((wj << 1) << (63 - sh));
     const uint64_t o0 = reverse_codes64(win0) ^ 0xAAAAAAAAAAAAAAAAull, o1 = reverse_codes64(win1) ^ 0xAAAAAAAAAAAAAAAAull;
     const u32x4 o = {(uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)o1, (uint32_t)(o1 >> 32)};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), rout, i * 16, 0, kSC0 | kSC1 | kNT);

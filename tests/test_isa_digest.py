@@ -39,11 +39,14 @@ def test_defaults_have_not_moved_since_round_3(isa):
     """splitting the lab variants out of the product must not touch the shipped kernels -- every block of
     round 3's committed digest is, line for line, a block of round 4's."""
     isa_digest, _ = isa
-    now = open(isa_digest.DIGEST).read()
-    old = open(isa_digest.DIGEST_R03).read()
-    blocks = [b for b in ("\n" + old).split("\n") if b]
-    for line in blocks:
-        assert line in now.split("\n"), "round 3's digest line is gone from round 4's: " + line
+    now = open(isa_digest.DIGEST).read().split("\n")
+    changed_on_purpose = ("reverse complement:",)  # round 4: its second load no longer waits for the first (branch-free funnel)
+    skip = False
+    for line in open(isa_digest.DIGEST_R03).read().split("\n"):
+        if line and not line.startswith((" ", "#")):
+            skip = line.startswith(changed_on_purpose)
+        if line and not skip:
+            assert line in now, "round 3's digest line is gone from round 4's: " + line
 
 
 def test_product_code_object_holds_no_lab_kernels(isa):
@@ -110,6 +113,19 @@ def test_5letter_codec_instruction_selection(isa):
     assert t["counts"]["v_pk_"] >= 40 and t["counts"]["v_perm_b32"] >= 40  # packed 16-bit /25, /5 and the weave
     assert t["store_policies"] == ["sc0 nt sc1"] and t["counts"]["buffer_store_dwordx4"] == 4
     assert 3400 <= m["group_segment_fixed_size"] <= 3584
+
+
+def test_every_tile_load_is_in_flight_before_the_first_wait(isa):
+    """A lane-masked partial load can end up behind an exec branch AND behind the s_waitcnt of the loads in front of it (the
+    5-letter window encoder did, round 4: its fourth load left only after half the wave had waited for the first three, two
+    dependent trips to memory per tile, 4.0 ms instead of 3.6 at 2^34 nt).  Every tile kernel the default paths launch must
+    have ALL its global loads issued when it first waits for memory."""
+    isa_digest, found = isa
+    for label, name in isa_digest.SHIPPED:
+        if label in ("hamming", "validate"):  # persistent loops: loads and waits alternate by design
+            continue
+        t, _, _ = _tile(isa_digest, found, name)
+        assert t["loads"] >= 1 and t["loads_before_first_wait"] == t["loads"], (label, t["loads_before_first_wait"], t["loads"])
 
 
 def test_packed_ops_instruction_selection(isa):
