@@ -25,7 +25,7 @@ DIGEST_R03 = os.path.join(ROOT, "profiles", "r03_isa_digest.txt")  # round 3's: 
 # the kernels the default paths launch (demangled prefix up to the template arguments' closing bracket)
 SHIPPED = [
     ("encode", "void cnt::n_to_bits_stream<64, 2, 1, 2, 19, false>"),
-    ("encode, any input phase", "void cnt::n_to_bits_window<1, 2, 19, false>"),
+    ("encode, any input phase", "void cnt::n_to_bits_window<4, 1, 2, 19, false>"),
     ("decode", "void cnt::bits_to_n_stream<64, 4, 4, 0, 19>"),
     ("decode, any output phase", "void cnt::bits_to_n_shifted<64, 4, 4, 0, 19>"),
     ("fused round trip", "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>"),

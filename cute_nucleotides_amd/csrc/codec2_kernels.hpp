@@ -307,7 +307,9 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
     CNT_ENCODE_EDGES_TAIL(BLOCK)
 }
 
-// WINDOW: variant 0's shape (one wave, 2 KiB in, 512 B out) for an input that starts at ANY
+// WINDOW: variant 0's one-wave shape with U loads per lane (U = 4: 4 KiB in, 1 KiB out -- the aligned kernel loses 0.6 % to
+// U = 2 at that size, profiles/r03_ab_step_encode_policies_plain_order.log, and the window's read-ahead line is 3 % of a
+// 4-KiB tile's reads instead of 6 % of a 2-KiB tile's) for an input that starts at ANY
 // byte address.  The wave loads the 128-B-aligned window that covers its tile -- `in` is the
 // caller's pointer rounded down to a line, `phase` (1..127) the bytes dropped -- so every load
 // is a whole-line access exactly as in the aligned kernel; each lane packs the ALIGNED 16 bytes
@@ -319,10 +321,10 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
 // caller's buffer.  (The OUTPUT side cannot be treated this way -- a store stream that is not
 // 64-B aligned costs ~30 %, profiles/r01_align_lab*.json -- so the launcher peels head words until
 // the stores are line-aligned and hands the resulting input phase here.)
-template <int C, int LAUX, int SAUX, bool STRICT>
+template <int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                           uint32_t n_tiles, uint32_t phase, uint32_t xs, EncodeEdges e) {
-    constexpr uint32_t TILE_IN = kWave * 2 * 16, TILE_OUT = TILE_IN / 4, SLACK = 144;
+    constexpr uint32_t TILE_IN = kWave * U * 16, TILE_OUT = TILE_IN / 4, SLACK = 144;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + SLACK);
     const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
@@ -330,18 +332,19 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
     const uint32_t q = phase >> 4, sh = (phase & 15) << 1;
     // lanes 0..q fetch the q+1 vectors behind the tile; the others aim past the descriptor's range,
     // which returns 0 without touching memory
-    const uint32_t off2 = lane <= q ? (2 * kWave + lane) * 16 : 0xFFFFFF00u;
-    const u32x4 v0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, LAUX));
-    const u32x4 v1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (kWave + lane) * 16, 0, LAUX));
-    const u32x4 v2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off2, 0, LAUX));
-    residency_pad[lane] = enc16<STRICT>(v0);
-    residency_pad[kWave + lane] = enc16<STRICT>(v1);
-    residency_pad[2 * kWave + lane] = enc16<STRICT>(v2);
+    const uint32_t off2 = lane <= q ? (U * kWave + lane) * 16 : 0xFFFFFF00u;
+    u32x4 v[U + 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (u * kWave + lane) * 16, 0, LAUX));
+    v[U] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off2, 0, LAUX));
+#pragma unroll
+    for (int u = 0; u <= U; ++u) residency_pad[u * kWave + lane] = enc16<STRICT>(v[u]);
     wave_lds_fence();
-    const uint32_t o0 = __builtin_amdgcn_alignbit(residency_pad[lane + q + 1], residency_pad[lane + q], sh);
-    const uint32_t o1 = __builtin_amdgcn_alignbit(residency_pad[kWave + lane + q + 1], residency_pad[kWave + lane + q], sh);
-    __builtin_amdgcn_raw_buffer_store_b32(o0, rout, lane * 4, 0, SAUX);
-    __builtin_amdgcn_raw_buffer_store_b32(o1, rout, (kWave + lane) * 4, 0, SAUX);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t o = __builtin_amdgcn_alignbit(residency_pad[u * kWave + lane + q + 1], residency_pad[u * kWave + lane + q], sh);
+        __builtin_amdgcn_raw_buffer_store_b32(o, rout, (u * kWave + lane) * 4, 0, SAUX);
+    }
     CNT_ENCODE_EDGES_TAIL(kWave)
 }
 

@@ -231,18 +231,20 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
 
 // The any-alignment companion of variant 0 (same shape, cache policy and residency cap):
 // `base` = input pointer rounded down to 128 B, `phase` = the 1..127 bytes dropped.
-constexpr uint32_t kWindowEncodeTile = 64 * 2 * 16;
+constexpr int kWindowEncodeU = 4;
+constexpr uint32_t kWindowEncodeTile = 64 * kWindowEncodeU * 16;
+constexpr uint32_t kEncodeStreamTile = 64 * 2 * 16;  // variant 0's tile: what "a whole number of tiles" means for small inputs
 constexpr uint32_t kWindowEncodeSlack = 144;  // bytes a tile may read behind its end
 template <bool STRICT>
 void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64);
-    const uint32_t lds = std::max(lds_for_cap(23), 768u);  // doubles as the kernel's 768-B exchange slab
+    const uint32_t lds = std::max(lds_for_cap(12), (kWindowEncodeU + 1) * 256u);  // doubles as the kernel's exchange slab (U + 1 rows of code dwords)
     const uint32_t xs = xcd_shift();
     e.tail_first = e.head_words + total_tiles * (kWindowEncodeTile / 32);
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         e.groups = first + n_tiles == total_tiles ? edge_groups(encode_edge_items(e), 64, n_tiles) : 0u;
-        hipLaunchKernelGGL((n_to_bits_window<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+        hipLaunchKernelGGL((n_to_bits_window<kWindowEncodeU, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e);
     }
 }
