@@ -34,7 +34,10 @@ written) over the kernel's average duration measured live with HIP ev
 launch stream; `roofline.traffic` = HBM bytes per launch measured by this run itself (two child `rocprofv3 --pmc`
 passes, FETCH_SIZE and WRITE_SIZE separately, calibrated on known-size probes; falls back to the committed
 profiles/hbm_traffic.json, and says so in `traffic_source`).  `cpu_baseline` times the oracle's ports of the reference's fastest AVX2
-paths (n_to_bits_movemask / bits_to_n_shuffle) on this box's host cores, rank 0, N=1 only.
+paths (n_to_bits_movemask / bits_to_n_shuffle) on this box's host cores: rank 0, at EVERY N (north_star: "next to the
+reference's own AVX2/BMI2 path timed on the GPU box's host cores in the same run", at 1, 2, 4 and 8 GPUs), after all GPU work of
+the line -- the host threads never compete with a rank that is still enqueueing.  At N > 1 the reference-faithful
+single-thread tables are left to the N = 1 line (`--cpu-seconds` bounds the leg either way).
 """
 import argparse
 import ctypes
@@ -54,10 +57,10 @@ for _p in (ROOT, os.path.join(ROOT, "bench")):
 # Everything that is not the contract itself lives in bench/ (VERDICT r03 next-8): bench_measure.py = statistics, HIP-event
 # timing loops and the extra blocks of the N = 1 line; bench_single_process.py = `--gpus N` without a launcher.  This file
 # keeps the arguments, the CPU-baseline leg (the only code allowed to touch oracle/), the timed region and the JSON line.
-from bench_measure import (BYTES_PER_NT, HBM_PEAK_GBS, HOST_TIER_LOG2, crossover, gbs, gpu_numa_node, host_placement,  # noqa: E402,F401
-                           load_probes, measure_ceilings, measure_codec5, host_tier_block, measure_config3_64gib, measure_configs_1gib, measure_host_tier,
-                           measure_packed_ops, measure_pcie,
-                           measure_traffic_live, numpy_pack, physical_cores, sockets, stats_ms, timed_calls, timed_queued)
+from bench_measure import (BYTES_PER_NT, HBM_PEAK_GBS, HOST_TIER_LOG2, crossover, device_row, first_contact_devices, gbs, gpu_numa_node,  # noqa: E402,F401
+                           host_placement, load_probes, measure_ceilings, measure_codec5, host_tier_block, measure_config3_64gib,
+                           measure_configs_1gib, measure_host_tier, measure_packed_ops, measure_pcie, measure_traffic_live, numpy_pack,
+                           physical_cores, require_free_hbm, sockets, stats_ms, timed_calls, timed_queued, traffic_for_line)
 
 def parse_args():
     p = argparse.ArgumentParser()
@@ -74,8 +77,10 @@ def parse_args():
     return p.parse_args()
 
 
-def cpu_baseline(seconds):
+def cpu_baseline(seconds, faithful_tables=True):
     """Time the oracle's x86 ports of the reference's best encoder/decoder on the host cores.
+    faithful_tables=False (the N > 1 lines) keeps the all-core and one-thread figures and skips the reference-harness
+    tables, which belong to -- and are on -- the N = 1 line.
     The oracle is used here only as the timed CPU baseline (kind 'port': the reference is Rust and
     cannot be built in this image).  Persistent threads: each owns one contiguous chunk and
     re-runs it until a common deadline (ctypes releases the GIL during the C call)."""
@@ -155,6 +160,24 @@ def cpu_baseline(seconds):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
+    both = lambda e, d: 2.0 / (1.0 / e + 1.0 / d)  # nt converted per second over an encode pass + a decode pass
+    summary = {
+        "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
+        "cores_detail": {"threads_timed": cores, "logical_cpus": cores, "physical_cores": physical,
+                         "sockets": sockets(), "note": "`cores` = timed threads = logical CPUs (SMT siblings included)"},
+        "sample": "%d Mi random ACGT nt (%d pinned threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
+                  "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"
+                  % (n_len >> 20, cores, seconds),
+        "encode_gnts": round(encN, 3), "decode_gnts": round(decN, 3),
+        "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3),
+                       "note": "one thread over the whole sample"},
+        "scalar_lut_encode_gnts_1thread": round(lut_enc, 3), "cpu_model": model,
+        "reference_toolchain": {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc"),
+                                "note": "kind is 'port' because the reference (Rust) cannot be built where no cargo/rustc exists"},
+    }
+    if not faithful_tables:
+        summary["reference_faithful_tables"] = "on the N = 1 line (reference_faithful_40k_GiBs, reference_faithful_GiBs_1thread_alloc_inclusive)"
+        return summary
     # reference-faithful rows: the reference's own bench input ("ATCG" x 10000, cache-resident), one
     # thread, output allocated inside every timed call (benches/bench_n_to_bits.rs:6-13) -- GiB/s of
     # nucleotides like criterion prints them, to sit beside README.md:344-366 (i9-9880H)
@@ -199,23 +222,7 @@ def cpu_baseline(seconds):
             per = L.cnt_port_time_alloc_inclusive(fn, src.ctypes.data, m, iters)
             row[name] = round(m / per / 2**30, 3)
         faithful_big["2^%d" % log2] = row
-    both = lambda e, d: 2.0 / (1.0 / e + 1.0 / d)  # nt converted per second over an encode pass + a decode pass
-    return {
-        "reference_faithful_40k_GiBs": faithful,
-        "reference_faithful_GiBs_1thread_alloc_inclusive": faithful_big,
-        "value": round(both(encN, decN), 3), "unit": "Gnt/s", "cores": cores, "kind": "port",
-        "cores_detail": {"threads_timed": cores, "logical_cpus": cores, "physical_cores": physical,
-                         "sockets": sockets(), "note": "`cores` = timed threads = logical CPUs (SMT siblings included)"},
-        "sample": "%d Mi random ACGT nt (%d pinned threads x >=16 Mi contiguous nt each, re-run until ~%.0f s total); "
-                  "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"
-                  % (n_len >> 20, cores, seconds),
-        "encode_gnts": round(encN, 3), "decode_gnts": round(decN, 3),
-        "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3),
-                       "note": "one thread over the whole sample"},
-        "scalar_lut_encode_gnts_1thread": round(lut_enc, 3), "cpu_model": model,
-        "reference_toolchain": {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc"),
-                                "note": "kind is 'port' because the reference (Rust) cannot be built where no cargo/rustc exists"},
-    }
+    return dict({"reference_faithful_40k_GiBs": faithful, "reference_faithful_GiBs_1thread_alloc_inclusive": faithful_big}, **summary)
 
 
 def main():
@@ -230,7 +237,7 @@ def main():
         if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
             from bench_single_process import main_single_process
 
-            return main_single_process(args)  # no launcher: one process drives the N devices (cnt_*_sharded_dev_enqueue)
+            return main_single_process(args, cpu_baseline)  # no launcher: one process drives the N devices (cnt_*_sharded_dev_enqueue)
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -287,14 +294,22 @@ def main():
     from cute_nucleotides_amd import devutil, sharding
 
     # ---- who am I: the device this rank drives ------------------------------------------------------
+    from cute_nucleotides_amd import _lib
+
     ident = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
-    ident.update(devutil.device_identity(local_rank))
-    props = torch.cuda.get_device_properties(local_rank)
-    ident["name"] = props.name
-    ident["uuid"] = str(getattr(props, "uuid", "")) or None
-    ident["hbm_GiB"] = round(props.total_memory / 2**30, 1)
+    ident.update(device_row(torch, devutil, _lib.lib(), local_rank))  # index, PCI address, NUMA node, name, UUID, HBM, cnt_chip_info
+
+    if world > 1:  # first contact, BEFORE anything is allocated: N ranks on N distinct devices (or labelled as folded), else stop
+        early = [None] * world
+        dist.all_gather_object(early, ident)
+        if rank == 0:
+            first_contact_devices(early, world, shared_gpu)
 
     n_per = 1 << args.log2_nt
+    # first contact: enough free HBM on THIS rank's device before anything is allocated (ranks folded
+    # onto one GPU by the test hook share it)
+    ident["hbm_before"] = require_free_hbm(torch, local_rank, (world if shared_gpu else 1) * 2.25 * n_per + (1 << 30),
+                                           "the timed buffers (2^%d nt in, packed, out%s)" % (args.log2_nt, " x %d folded ranks" % world if shared_gpu and world > 1 else ""))
     n_global = n_per * world
     lo, hi = sharding.partition(n_global, world)[rank]  # contiguous chunk on a word boundary
     assert (lo, hi) == sharding.shard_range_c(n_global, world, rank)  # the C library cuts at the same places
@@ -483,25 +498,11 @@ def main():
         value = nt_per_step * args.steps / elapsed / 1e9
         enc_gbs = gbs(BYTES_PER_NT * n_len, enc_ms)
         dec_gbs = gbs(BYTES_PER_NT * n_len, dec_ms)
-        traffic, traffic_source, live = None, None, None
-        if world == 1 and extras and not args.no_live_traffic and not os.environ.get("ROCPROFILER_SDK_TOOL_LIBRARIES") and not os.environ.get("ROCP_TOOL_LIBRARIES"):
-            live = measure_traffic_live(args.log2_nt)  # all of this process's device buffers are free by now
-            if "error" not in live:
-                traffic = {"encode_bytes_per_launch": live["encode"]["hbm_bytes"], "decode_bytes_per_launch": live["decode"]["hbm_bytes"]}
-                traffic_source = ("measured by this run on this box: child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes "
-                                  "over bench/pmc_workload.py --codec-only (2 launches each), calibrated on read-only / write-only probes of "
-                                  "known size in the same pass (fetch x%.3f, write x%.3f)" % (live["calibration"]["fetch_scale"], live["calibration"]["write_scale"]))
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if traffic is None and os.path.exists(tpath) and args.log2_nt == 34:
-            try:
-                traffic = json.load(open(tpath))
-                traffic_source = ("static: profiles/hbm_traffic.json, from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
-                                  "calibrated; bench/profile.sh) -- NOT measured by this run; kernels recorded there: %s" %
-                                  (traffic.get("source"), traffic.get("kernels", "the shipped defaults of that round")))
-            except Exception:
-                traffic = None
+        # every buffer of this process is free by now; at N > 1 the child passes see rank 0's device only
+        traffic, traffic_source, live = traffic_for_line(args.log2_nt, world, extras and not args.no_live_traffic,
+                                                         child_device=local_rank if world > 1 else None)
         span = lambda key: {"min": min(r[key] for r in rows), "max": max(r[key] for r in rows)}
-        uuids = {r.get("uuid") or r["pci_bus_id"] for r in rows}
+        devices = first_contact_devices(rows, world, shared_gpu, control_plane=backend if world > 1 else None, processes=world)
         line = {
             "metric": "Gnt/s encode+decode on 16 GiB random ACGT; % HBM read roofline at 1/8 GPU",
             "value": round(value, 3), "unit": "Gnt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -542,8 +543,7 @@ def main():
             "roofline_over_ranks": {"encode_frac": span("encode_frac"), "decode_frac": span("decode_frac"),
                                     "encode_read_view_frac": span("encode_read_view_frac")},
             "ranks": rows,
-            "devices": {"distinct": len(uuids), "shared_gpu_test_hook": shared_gpu,
-                        "data_path_collective": None, "control_plane": backend if world > 1 else None},
+            "devices": devices,
             "verified": verified,
             "value_definition": "nucleotides converted per second over all ranks: each step encodes nt_per_gpu and decodes "
                                 "nt_per_gpu on every rank (nt_per_step = 2 x n_gpus x nt_per_gpu); equals the harmonic mean "
@@ -618,9 +618,11 @@ def main():
                 "per_gpu_read_view_frac": {"min": round(min(gbs(s["nt"], s["encode_ms"]["median"]) for s in sh) / HBM_PEAK_GBS, 4),
                                            "max": round(max(gbs(s["nt"], s["encode_ms"]["median"]) for s in sh) / HBM_PEAK_GBS, 4)},
             }
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-            if extras:
+        if args.cpu_seconds > 0:  # every N (north_star: the CPU path timed in the same run at 1, 2, 4 and 8 GPUs); all GPU work is done
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, faithful_tables=world == 1)
+            if world > 1:
+                line["cpu_baseline"]["when"] = "after the timed region and every extra of all %d ranks (they wait at the final barrier)" % world
+            if extras and world == 1:
                 cpu_rows = line["cpu_baseline"].get("reference_faithful_GiBs_1thread_alloc_inclusive") or {}
                 line["host_tier"] = host_tier_block(torch, args.seed, cpu_rows, ident.get("pci_bus_id"))  # bench/bench_measure.py
         print(json.dumps(line), flush=True)

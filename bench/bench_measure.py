@@ -494,7 +494,90 @@ def crossover(host_rows, cpu_rows):
     return out
 
 
-def measure_traffic_live(log2_nt, timeout_s=90):
+# ---- first contact with real multi-device hardware: every N > 1 line diagnoses itself -------------
+EXPECTED_CHIP = {"compute_units": 256, "lds_bytes_per_cu": 163840, "xcds": 8}  # an MI355X in SPX mode (cnt_chip_info)
+
+
+def chip_info(L, index):
+    """what the library's launch geometry for this device is sized from (cnt_chip_info): CUs, LDS per CU, XCDs"""
+    v = [ctypes.c_int(0) for _ in range(3)]
+    rc = L.cnt_chip_info(index, *[ctypes.byref(x) for x in v])
+    if rc != 0:
+        return {"error": "cnt_chip_info -> %d" % rc}
+    return dict(zip(("compute_units", "lds_bytes_per_cu", "xcds"), (x.value for x in v)))
+
+
+def device_row(torch, devutil, L, index):
+    """identity of one visible device for a `ranks` row: index, PCI address, NUMA node, name, UUID, HBM size, chip geometry"""
+    ident = dict(devutil.device_identity(index))
+    props = torch.cuda.get_device_properties(index)
+    ident.update({"name": props.name, "uuid": str(getattr(props, "uuid", "")) or None, "hbm_GiB": round(props.total_memory / 2**30, 1),
+                  "chip": chip_info(L, index)})
+    return ident
+
+
+def first_contact_devices(rows, n_gpus, shared_hook, **extra):
+    """The `devices` block of a bench line, and the refusal of a run that is not what it says: N ranks must sit on N
+    DISTINCT devices (UUID, else PCI address) unless the test hook that folds them onto fewer is on -- a folded run
+    mislabelled as an N-GPU line is the one silent failure the first hardware run could have.  A device whose chip geometry
+    is not an SPX-mode MI355X's (a partitioned mode: fewer CUs / XCDs per visible device) stays legal but is named on the
+    line, next to every rank's own `chip`."""
+    ids = [r.get("uuid") or r["pci_bus_id"] for r in rows]
+    distinct = len(set(ids))
+    if len(rows) != n_gpus:
+        raise SystemExit("bench: %d report rows for %d GPUs" % (len(rows), n_gpus))
+    if distinct != n_gpus and not shared_hook:
+        dup = sorted({i for i in ids if ids.count(i) > 1})
+        raise SystemExit("bench: --gpus %d but the ranks sit on %d distinct device(s) (shared: %s) and the fold-onto-one-GPU test "
+                         "hook is off: refusing to print a folded run as an %d-GPU line" % (n_gpus, distinct, ", ".join(map(str, dup)), n_gpus))
+    odd = [{"rank": r.get("rank"), "pci_bus_id": r.get("pci_bus_id"), "chip": r.get("chip")} for r in rows
+           if r.get("chip") and r["chip"] != EXPECTED_CHIP]
+    block = {"distinct": distinct, "expected_distinct": n_gpus, "shared_gpu_test_hook": bool(shared_hook),
+             "numa_nodes": sorted({r.get("numa_node") for r in rows if r.get("numa_node") is not None}),
+             "not_an_spx_mi355x": odd, "data_path_collective": None}
+    block.update(extra)
+    return block
+
+
+def require_free_hbm(torch, index, need_bytes, what):
+    """fail loudly BEFORE allocating: another tenant, a partitioned device or a leaked context on one of N devices would
+    otherwise surface as an out-of-memory error from the middle of the run"""
+    free, total = torch.cuda.mem_get_info(index)
+    if free < need_bytes:
+        raise SystemExit("bench: device %d has %.1f of %.1f GiB of HBM free, %s needs %.1f GiB" %
+                         (index, free / 2**30, total / 2**30, what, need_bytes / 2**30))
+    return {"free_GiB": round(free / 2**30, 1), "total_GiB": round(total / 2**30, 1)}
+
+
+def traffic_for_line(log2_nt, n_gpus, allow_live, child_device=None):
+    """(traffic, traffic_source, live): HBM bytes per launch of the two timed kernels for `roofline.traffic` -- measured by
+    this run (two child rocprofv3 --pmc passes on rank 0's device, every buffer of this process freed first) or, when that
+    is not possible / not wanted, the committed profiles/hbm_traffic.json with a label that says so.  The same code at
+    every N: at N > 1 the figure is rank 0's device's (the kernels and sizes are the same on every rank)."""
+    traffic, source, live = None, None, None
+    if allow_live and not os.environ.get("ROCPROFILER_SDK_TOOL_LIBRARIES") and not os.environ.get("ROCP_TOOL_LIBRARIES"):
+        live = measure_traffic_live(log2_nt, child_device=child_device)
+        if "error" not in live:
+            traffic = {"encode_bytes_per_launch": live["encode"]["hbm_bytes"], "decode_bytes_per_launch": live["decode"]["hbm_bytes"]}
+            source = ("measured by this run on this box%s: child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes "
+                      "over bench/pmc_workload.py --codec-only (2 launches each), calibrated on read-only / write-only probes of "
+                      "known size in the same pass (fetch x%.3f, write x%.3f)" %
+                      (" (rank 0's device; same kernels and sizes on all %d)" % n_gpus if n_gpus > 1 else "",
+                       live["calibration"]["fetch_scale"], live["calibration"]["write_scale"]))
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if traffic is None and os.path.exists(tpath) and log2_nt == 34:
+        try:
+            traffic = json.load(open(tpath))
+            source = ("static%s: profiles/hbm_traffic.json, from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                      "calibrated; bench/profile.sh) -- NOT measured by this run; kernels recorded there: %s" %
+                      (", N = 1 measurement quoted on an N = %d line" % n_gpus if n_gpus > 1 else "",
+                       traffic.get("source"), traffic.get("kernels", "the shipped defaults of that round")))
+        except Exception:  # noqa: BLE001
+            traffic = None
+    return traffic, source, live
+
+
+def measure_traffic_live(log2_nt, timeout_s=90, child_device=None):
     """HBM bytes per launch of the two timed kernels, measured by THIS run on THIS box: two child processes of
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has 4 counter slots,
     3 + 2 do not fit; counters are never combined with any other tracing domain) over bench/pmc_workload.py
@@ -513,13 +596,28 @@ def measure_traffic_live(log2_nt, timeout_s=90):
 
     tmp = tempfile.mkdtemp(prefix="cnt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CNT_BENCH_SHARE_GPU"):
+        env.pop(k, None)  # the child is a plain one-device process, whatever launched the parent
+    if child_device is not None:  # N > 1: the child sees rank 0's device only (an entry of the parent's own visibility list)
+        vis = [x for x in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip()]
+        env["HIP_VISIBLE_DEVICES"] = vis[child_device] if child_device < len(vis) else str(child_device)
     try:
         csvs = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
                    sys.executable, os.path.join(ROOT, "bench", "pmc_workload.py"), "--log2-nt", str(log2_nt), "--reps", "2", "--codec-only"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            # its own session: a timeout takes rocprofv3 AND the workload it spawned, never a GPU process left behind
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                out_text, _ = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.communicate()
+                return {"error": "rocprofv3 --pmc %s: no result within %d s (process group killed)" % (counter, timeout_s)}
+            r = subprocess.CompletedProcess(cmd, proc.returncode, out_text)
             csvs[counter] = os.path.join(out, "pmc_counter_collection.csv")
             if r.returncode != 0 or not os.path.exists(csvs[counter]):
                 return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout[-300:])}

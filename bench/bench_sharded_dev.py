@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import cute_nucleotides_amd as cn  # noqa: E402,F401
-from cute_nucleotides_amd import devutil, sharding  # noqa: E402
+from cute_nucleotides_amd import _lib, devutil, sharding  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--ndev", type=int, default=0, help="shards (0 = all visible devices)")
@@ -39,7 +39,8 @@ ndev = a.ndev or count
 alias = a.alias
 if ndev > count and not alias:
     raise SystemExit("%d shards need %d devices (%d visible); --alias folds them for a code-path run" % (ndev, ndev, count))
-if alias:
+if alias:  # the switch exists in the test-hooks build only (tests/libcute_nt_hip_hooks.so); the product runs shard k on device k
+    _lib.use_build("hooks")
     sharding.alias_devices(True)
 n_global = ndev << a.log2_nt
 parts = [sharding.shard_range_c(n_global, ndev, k) for k in range(ndev)]

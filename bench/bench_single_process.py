@@ -21,10 +21,11 @@ import os
 import statistics
 import time
 
-from bench_measure import BYTES_PER_NT, HBM_PEAK_GBS, gbs, numpy_pack, stats_ms
+from bench_measure import BYTES_PER_NT, HBM_PEAK_GBS, device_row, first_contact_devices, gbs, numpy_pack, require_free_hbm, stats_ms, traffic_for_line
 
 
-def main_single_process(args):
+def main_single_process(args, cpu_baseline=None):
+    """cpu_baseline: bench.py's CPU leg (the only code allowed to touch oracle/), handed in so that this line carries the key too"""
     import numpy as np
     import torch
 
@@ -36,10 +37,14 @@ def main_single_process(args):
     N = args.gpus
     visible = torch.cuda.device_count()
     shared_gpu = os.environ.get("CNT_BENCH_SHARE_GPU") == "1"  # test support, never set by the driver: fold N shards onto the visible devices
-    if visible < N:
+    folded = visible < N
+    if folded:
         if not shared_gpu:
             raise SystemExit("--gpus %d: only %d HIP device(s) visible to this process (one process drives all N devices; "
                              "a torch.distributed.run launch with %d ranks works too)" % (N, visible, N))
+        # the switch that folds shard k onto device k % visible exists in the test-hooks build only
+        # (tests/libcute_nt_hip_hooks.so, -DCNT_TEST_HOOKS: the product's kernels + cnt_test_*); the product runs shard k on device k
+        _lib.use_build("hooks")
         sharding.alias_devices(True)
     L = _lib.lib()
     n_per = 1 << args.log2_nt
@@ -48,6 +53,14 @@ def main_single_process(args):
     assert parts == sharding.partition(n_global, N)
     devs = [torch.device("cuda", k % visible) for k in range(N)]
     per_dev = math.ceil(N / min(N, visible))
+    # first contact: who are the N devices, are they N DISTINCT ones, what geometry does the library size
+    # its launches from on each, and is there room -- all BEFORE anything is allocated; the rows go onto the line as `ranks`
+    idents = [device_row(torch, devutil, L, k % visible) for k in range(N)]
+    for k, row in enumerate(idents):
+        row.update({"rank": k})
+    first_contact_devices(idents, N, folded and shared_gpu)  # raises on a folded run that is not labelled as one
+    hbm_before = [require_free_hbm(torch, i, per_dev * 2.25 * n_per + (1 << 30), "%d shard(s) of 2^%d nt (in, packed, out)" % (per_dev, args.log2_nt))
+                  for i in range(min(N, visible))]
 
     def sync_all():
         for i in range(min(N, visible)):
@@ -69,9 +82,17 @@ def main_single_process(args):
     d_in = [torch.empty(x, dtype=torch.uint8, device=d) for x, d in zip(lens_l, devs)]
     d_pk = [torch.empty(w, dtype=torch.int64, device=d) for w, d in zip(words_l, devs)]
     d_out = [torch.empty(x, dtype=torch.uint8, device=d) for x, d in zip(lens_l, devs)]
-    for t, (lo, _) in zip(d_in, parts):
-        devutil.fill_random_acgt(t, args.seed, first_nt=lo)
-    sync_all()
+    # the generator runs on a torch stream per shard and the HOST DOES NOT WAIT FOR IT: the queue is ordered behind each
+    # shard's `filled` event on the device (cnt_sharded_dev_wait_event) -- generator -> encode -> decode
+    # on N devices from one thread without a host synchronisation in between
+    gen_streams = [torch.cuda.Stream(device=d) for d in devs]
+    filled = []
+    for t, (lo, _), st in zip(d_in, parts, gen_streams):
+        with torch.cuda.device(t.device), torch.cuda.stream(st):
+            devutil.fill_random_acgt(t, args.seed, first_nt=lo)
+            e = torch.cuda.Event()
+            e.record(st)
+            filled.append(e)
     a_in, a_pk, a_out, a_len, a_words = arrays(d_in), arrays(d_pk), arrays(d_out), sizes(lens_l), sizes(words_l)
 
     def queue_steps(q, steps, ins, lens, pks, words, outs):
@@ -82,33 +103,42 @@ def main_single_process(args):
             _lib.check(L.cnt_bits_to_n_sharded_dev_enqueue(q, pks, words, lens, outs, 0))
         return time.perf_counter() - t
 
+    per_batch = _lib.CNT_QUEUE_MAX_TIMED_OPS // 2  # a timed queue holds 4096 ops per batch: K <= 2048 steps are ONE batch, ONE wait
+
+    def run_steps(q, steps, ins, lens, pks, words, outs, n):
+        """`steps` steps in batches of <= per_batch (queued back to back, one wait per batch); (wall seconds from the first
+        enqueue to the end of the last wait -- the event read-back between batches is outside the clock --, host seconds
+        enqueueing, per-step per-shard encode ms, decode ms)"""
+        wall, host, enc, dec, done = 0.0, 0.0, [], [], 0
+        while done < steps:
+            b = min(per_batch, steps - done)
+            t = time.perf_counter()
+            host += queue_steps(q, b, ins, lens, pks, words, outs)  # returns with (almost) everything still queued
+            _lib.check(L.cnt_sharded_dev_wait(q, None))             # ONE wait for the batch on all devices
+            wall += time.perf_counter() - t
+            for k in range(b):
+                e, d = (ctypes.c_float * n)(), (ctypes.c_float * n)()
+                _lib.check(L.cnt_sharded_dev_op_ms(q, 2 * k, e))
+                _lib.check(L.cnt_sharded_dev_op_ms(q, 2 * k + 1, d))
+                enc.append(list(e))
+                dec.append(list(d))
+            done += b
+        return wall, host, enc, dec
+
     q = open_queue(N)
+    for k, e in enumerate(filled):
+        _lib.check(L.cnt_sharded_dev_wait_event(q, k, ctypes.c_void_p(e.cuda_event)))  # shard k's stream waits for its generator, on the device
     if args.warmup:
-        queue_steps(q, args.warmup, a_in, a_len, a_pk, a_words, a_out)
-        _lib.check(L.cnt_sharded_dev_wait(q, None))
-    sync_all()
-    t0 = time.perf_counter()
-    host_s = queue_steps(q, args.steps, a_in, a_len, a_pk, a_words, a_out)  # returns with (almost) everything still queued
-    _lib.check(L.cnt_sharded_dev_wait(q, None))                             # ONE wait for all K steps on all devices
-    elapsed = time.perf_counter() - t0
-    ms_e, ms_d = [], []
-    for k in range(args.steps):
-        e, d = (ctypes.c_float * N)(), (ctypes.c_float * N)()
-        _lib.check(L.cnt_sharded_dev_op_ms(q, 2 * k, e))
-        _lib.check(L.cnt_sharded_dev_op_ms(q, 2 * k + 1, d))
-        ms_e.append(list(e))
-        ms_d.append(list(d))
+        run_steps(q, args.warmup, a_in, a_len, a_pk, a_words, a_out, N)  # queued while the generators may still be running
+    sync_all()  # the timed region starts from idle devices (the contract's synchronize-on-both-sides), not for ordering
+    elapsed, host_s, ms_e, ms_d = run_steps(q, args.steps, a_in, a_len, a_pk, a_words, a_out, N)  # the wait drains every device
 
     # the same K steps for shard 0 alone, through a one-shard queue: what one device costs without the fan-out
     q1 = open_queue(1)
     one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
     b_in, b_pk, b_out, b_len, b_words = one(d_in[0]), one(d_pk[0]), one(d_out[0]), sizes(lens_l[:1], 1), sizes(words_l[:1], 1)
-    queue_steps(q1, max(1, args.warmup), b_in, b_len, b_pk, b_words, b_out)
-    _lib.check(L.cnt_sharded_dev_wait(q1, None))
-    t1 = time.perf_counter()
-    queue_steps(q1, args.steps, b_in, b_len, b_pk, b_words, b_out)
-    _lib.check(L.cnt_sharded_dev_wait(q1, None))
-    elapsed_one = time.perf_counter() - t1
+    run_steps(q1, max(1, args.warmup), b_in, b_len, b_pk, b_words, b_out, 1)
+    elapsed_one = run_steps(q1, args.steps, b_in, b_len, b_pk, b_words, b_out, 1)[0]
     _lib.check(L.cnt_sharded_dev_close(q1))
     scaling_overhead_us = (elapsed - per_dev * elapsed_one) / args.steps * 1e6
 
@@ -126,6 +156,35 @@ def main_single_process(args):
         ok = ok and bool((kat_bits.cpu().numpy().view(np.uint64) == np.uint64(0xD8D8D8D8D8D8D8D8)).all())
         verified = bool(ok)
         del kat, kat_bits
+
+    # ---- BASELINE.json configs[3] in passing: the FUSED round trip of every shard through the same queue (not part of value) ----
+    fused_rows, ceilings = None, None
+    if not args.no_extras:
+        sums = [devutil.checksum_words(t) for t in d_pk] if verified is not None else None
+        reps = 5
+        for _ in range(reps + 1):  # one warm-up op + five timed ones, queued back to back, one wait
+            _lib.check(L.cnt_round_trip_sharded_dev_enqueue(q, a_in, a_len, a_pk, a_words, a_out, 0))
+        _lib.check(L.cnt_sharded_dev_wait(q, None))
+        f_ms = []
+        for r in range(1, reps + 1):
+            row = (ctypes.c_float * N)()
+            _lib.check(L.cnt_sharded_dev_op_ms(q, r, row))
+            f_ms.append(list(row))
+        fused_rows = [stats_ms([f_ms[r][k] for r in range(reps)]) for k in range(N)]
+        if verified is not None:  # the fused kernel's own outputs: same packed words, same decoded text, on every shard
+            f_ok = all(devutil.count_mismatch(a, b) == 0 for a, b in zip(d_in, d_out)) and [devutil.checksum_words(t) for t in d_pk] == sums
+            verified = verified and f_ok
+            for st in fused_rows:
+                st["verified"] = f_ok
+        # same-run ceilings on device 0 (arithmetic-free streams issued like the shipped kernels, over shard 0's own buffers)
+        from bench_measure import load_probes, measure_ceilings
+
+        P = load_probes()
+        if P is not None and lens_l[0] % 16384 == 0 and lens_l[0] <= (1 << 35):
+            with torch.cuda.device(devs[0]):
+                ceilings = measure_ceilings(torch, P, d_in[0], d_out[0], lens_l[0])
+        else:
+            ceilings = {"error": "bench/libcnt_probes.so not built (run __graft_entry__.build())" if P is None else "size not probe-able"}
 
     # ---- BASELINE.json configs[4]: 2^35 nt per GPU through the same queue ------------------------------------------------
     del d_out, d_pk, d_in, a_in, a_pk, a_out, b_in, b_pk, b_out
@@ -171,7 +230,6 @@ def main_single_process(args):
             del s_in, s_pk
         else:
             shard_rows = [{"skipped": "needs %.0f GiB of free HBM per device" % ((per_dev * 2.3 * s_len + (4 << 30)) / 2**30)}] * N
-    _lib.check(L.cnt_sharded_dev_close(q))
 
     rows = []
     for k in range(N):
@@ -179,17 +237,23 @@ def main_single_process(args):
         dec_list = [ms_d[i][k] for i in range(args.steps)]
         enc_ms, dec_ms = statistics.fmean(enc_list), statistics.fmean(dec_list)
         ident = {"rank": k, "local_rank": k, "pid": os.getpid()}
-        ident.update(devutil.device_identity(k % visible))
-        props = torch.cuda.get_device_properties(k % visible)
-        ident.update({"name": props.name, "uuid": str(getattr(props, "uuid", "")) or None, "hbm_GiB": round(props.total_memory / 2**30, 1)})
+        ident.update(idents[k])  # device index, PCI address, NUMA node, name, UUID, HBM size, cnt_chip_info -- taken before anything ran
+        ident["hbm_before"] = hbm_before[k % visible]
         ident.update({
             "nt": lens_l[k], "first_nt": parts[k][0], "encode_ms": stats_ms(enc_list), "decode_ms": stats_ms(dec_list),
             "encode_gnts": round(lens_l[k] / (enc_ms * 1e-3) / 1e9, 1), "decode_gnts": round(lens_l[k] / (dec_ms * 1e-3) / 1e9, 1),
             "encode_frac": round(gbs(BYTES_PER_NT * lens_l[k], enc_ms) / HBM_PEAK_GBS, 4),
             "decode_frac": round(gbs(BYTES_PER_NT * lens_l[k], dec_ms) / HBM_PEAK_GBS, 4),
             "encode_read_view_frac": round(gbs(lens_l[k], enc_ms) / HBM_PEAK_GBS, 4),
-            "fused_ms_median": None, "configs4_shard": shard_rows[k]})
+            "fused_ms_median": fused_rows[k]["median"] if fused_rows else None, "configs4_shard": shard_rows[k]})
         rows.append(ident)
+
+    _lib.check(L.cnt_sharded_dev_close(q))
+    for i in range(min(N, visible)):
+        with torch.cuda.device(i):
+            torch.cuda.empty_cache()
+    # HBM bytes per launch for roofline.traffic: live on device 0 (every buffer of this process is free), else the committed N = 1 figure, labelled
+    traffic, traffic_source, live = traffic_for_line(args.log2_nt, N, not args.no_extras and not args.no_live_traffic, child_device=0)
 
     nt_per_step = 2 * n_global
     value = nt_per_step * args.steps / elapsed / 1e9
@@ -197,10 +261,10 @@ def main_single_process(args):
     enc_ms0, dec_ms0 = r0["encode_ms"]["mean"], r0["decode_ms"]["mean"]
     enc_slow, dec_slow = max(r["encode_ms"]["mean"] for r in rows), max(r["decode_ms"]["mean"] for r in rows)
     span = lambda key: {"min": min(r[key] for r in rows), "max": max(r[key] for r in rows)}
-    roof = lambda name, ms, st: {
+    roof = lambda name, ms, st, key: {
         "kernel": name, "bound": "hbm", "achieved": round(gbs(BYTES_PER_NT * lens_l[0], ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(gbs(BYTES_PER_NT * lens_l[0], ms) / HBM_PEAK_GBS, 4), "traffic": None,
-        "traffic_source": "not measured at N > 1 (the N = 1 line measures it live with rocprofv3 --pmc)", "avg_kernel_ms": round(ms, 4), "kernel_ms": st,
+        "frac": round(gbs(BYTES_PER_NT * lens_l[0], ms) / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get(key),
+        "traffic_source": traffic_source, "avg_kernel_ms": round(ms, 4), "kernel_ms": st,
         "frac_at_median": round(gbs(BYTES_PER_NT * lens_l[0], st["median"]) / HBM_PEAK_GBS, 4),
         "frac_at_min": round(gbs(BYTES_PER_NT * lens_l[0], st["min"]) / HBM_PEAK_GBS, 4),
         "algorithmic_bytes_per_launch": int(BYTES_PER_NT * lens_l[0]),
@@ -216,7 +280,9 @@ def main_single_process(args):
             "nt_per_gpu": n_per, "nt_per_step": nt_per_step, "seed": hex(args.seed),
             "sharding": "contiguous chunks on word boundaries (cnt_shard_range), shard k resident on device k, no data-path collective",
             "launch": "single process, enqueue-only: all %d steps (encode + decode per shard) queued on one library stream per shard through "
-                      "cnt_*_sharded_dev_enqueue, ONE cnt_sharded_dev_wait" % args.steps,
+                      "cnt_*_sharded_dev_enqueue, ONE cnt_sharded_dev_wait%s; every shard's stream ordered behind its generator's torch stream "
+                      "on the device (cnt_sharded_dev_wait_event), no host synchronisation between generator and codec"
+                      % (args.steps, "" if args.steps <= per_batch else " per %d steps" % per_batch),
             "encode_kernel": dict(devutil.variants("encode"))[devutil.get_tuning("encode")],
             "decode_kernel": dict(devutil.variants("decode"))[devutil.get_tuning("decode")],
         },
@@ -232,13 +298,14 @@ def main_single_process(args):
         "encode_gnts_per_gpu": round(lens_l[0] / (enc_ms0 * 1e-3) / 1e9, 3), "decode_gnts_per_gpu": round(lens_l[0] / (dec_ms0 * 1e-3) / 1e9, 3),
         "encode_gnts_all_gpus": round(n_global / (enc_slow * 1e-3) / 1e9, 3), "decode_gnts_all_gpus": round(n_global / (dec_slow * 1e-3) / 1e9, 3),
         "hbm_read_roofline_frac_encode_per_gpu": round(n_per / (enc_slow * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": dict(roof("n_to_bits (encode)", enc_ms0, r0["encode_ms"]),
+        "roofline": dict(roof("n_to_bits (encode)", enc_ms0, r0["encode_ms"], "encode_bytes_per_launch"),
                          read_only_view={"achieved": round(gbs(lens_l[0], enc_ms0), 1), "frac": round(gbs(lens_l[0], enc_ms0) / HBM_PEAK_GBS, 4)}),
-        "roofline_decode": roof("bits_to_n (decode)", dec_ms0, r0["decode_ms"]),
+        "roofline_decode": roof("bits_to_n (decode)", dec_ms0, r0["decode_ms"], "decode_bytes_per_launch"),
+        "traffic_live": live,
         "roofline_over_ranks": {"encode_frac": span("encode_frac"), "decode_frac": span("decode_frac"), "encode_read_view_frac": span("encode_read_view_frac")},
         "ranks": rows,
-        "devices": {"distinct": len({r.get("uuid") or r["pci_bus_id"] for r in rows}), "visible": visible, "shared_gpu_test_hook": shared_gpu and visible < N,
-                    "data_path_collective": None, "control_plane": None, "processes": 1},
+        "devices": first_contact_devices(rows, N, folded and shared_gpu, visible=visible, control_plane=None, processes=1,
+                                         library_build=_lib.active_build()),
         "verified": verified,
         "value_definition": "nucleotides converted per second over all devices: each step encodes nt_per_gpu and decodes nt_per_gpu on every "
                             "device (nt_per_step = 2 x n_gpus x nt_per_gpu); wall clock around the K queued steps and the one wait, "
@@ -264,4 +331,28 @@ def main_single_process(args):
             "per_gpu_read_view_frac": {"min": round(min(gbs(x["nt"], x["encode_ms"]["median"]) for x in sh) / HBM_PEAK_GBS, 4),
                                        "max": round(max(gbs(x["nt"], x["encode_ms"]["median"]) for x in sh) / HBM_PEAK_GBS, 4)},
         }
+    if fused_rows:
+        f0 = fused_rows[0]
+        fgbs = gbs(2.25 * lens_l[0], f0["median"])
+        line["fused_round_trip"] = {
+            "what": "cnt_round_trip_sharded_dev_enqueue: one pass per shard reads the ASCII and writes packed words + decoded ASCII (BASELINE.json "
+                    "configs[3] at the metric size), all shards at once through the same queue; measured after the timed region, not part of value",
+            "ms": f0["median"], "ms_stats": f0, "nt_converted_gnts": round(2 * lens_l[0] / (f0["median"] * 1e-3) / 1e9, 3), "bytes_per_nt": 2.25,
+            "achieved": round(fgbs, 1), "unit": "GB/s", "frac": round(fgbs / HBM_PEAK_GBS, 4), "of": "device 0's shard",
+            "frac_over_ranks": {"min": round(min(gbs(2.25 * n, st["median"]) for n, st in zip(lens_l, fused_rows)) / HBM_PEAK_GBS, 4),
+                                "max": round(max(gbs(2.25 * n, st["median"]) for n, st in zip(lens_l, fused_rows)) / HBM_PEAK_GBS, 4)}}
+    if ceilings is not None:
+        line["ceilings"] = {"what": "no-arithmetic streams issued exactly like the shipped kernels (bench/probes.hip probe_shipped), same process, shard 0's "
+                                    "buffers on device 0, median of 5 launches each; GB/s of all bytes moved", "rank0": ceilings}
+        if "error" not in ceilings:
+            e_gbs, d_gbs = gbs(BYTES_PER_NT * lens_l[0], enc_ms0), gbs(BYTES_PER_NT * lens_l[0], dec_ms0)
+            line["ceilings"]["encode_vs"] = {"of_read4_write1_ceiling": round(e_gbs / ceilings["read4_write1_encode_shape"]["GBs"], 4),
+                                             "read_only_view_of_read_only_ceiling": round(gbs(lens_l[0], enc_ms0) / ceilings["read_only"]["GBs"], 4)}
+            line["ceilings"]["decode_vs"] = {"of_read1_write4_ceiling": round(d_gbs / ceilings["read1_write4_decode_shape"]["GBs"], 4)}
+    line["codec5"] = line["packed_ops"] = {"on": "the N = 1 line (SURVEY 8 f-1 / f-4 at the metric size; per-GPU work does not change with N)"}
+    if cpu_baseline is not None and args.cpu_seconds > 0:
+        # north_star: the reference's AVX2 path timed on this box's host cores IN THE SAME RUN, at every N; after all GPU work
+        # of the line, so its threads never compete with the thread that enqueues for N devices
+        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, faithful_tables=False)
+        line["cpu_baseline"]["when"] = "after the timed region and every extra (all devices idle)"
     print(json.dumps(line), flush=True)

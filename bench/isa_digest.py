@@ -49,12 +49,12 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def assembly(lab=False):
+def assembly(lab=False, hooks=False):
     """demangled gfx950 assembly of the library's device code, same flags as cute_nucleotides_amd/build.py (the PRODUCT
-    build; lab=True adds -DCNT_LAB_VARIANTS)"""
+    build; lab=True adds -DCNT_LAB_VARIANTS, hooks=True -DCNT_TEST_HOOKS)"""
     with tempfile.TemporaryDirectory(prefix="cnt_isa_") as tmp:
         out = os.path.join(tmp, "cute_nt.s")
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + (["-DCNT_LAB_VARIANTS"] if lab else []) +
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + (["-DCNT_LAB_VARIANTS"] if lab else []) + (["-DCNT_TEST_HOOKS"] if hooks else []) +
                               ["-o", out, SRC], stderr=subprocess.DEVNULL)
         cxxfilt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
         if not os.path.exists(cxxfilt):

@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(HERE, "libcute_nt_hip.so")
 # never loaded unless a bench script or a test asks for it with use_lab_build(): the product library has no run-time kernel
 # selection (cnt_set_tuning answers CNT_EINVAL there).
 LAB_LIB_PATH = os.path.join(os.path.dirname(HERE), "bench", "libcute_nt_hip_lab.so")
+# The TEST-HOOKS build (-DCNT_TEST_HOOKS: the product's kernels + the three cnt_test_* hooks), under tests/: what the N > 1
+# sharded tests load to fold shards onto a 1-GPU box.  The product library exports no hook and holds no switch.
+HOOKS_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcute_nt_hip_hooks.so")
 
 CNT_OK, CNT_EINVAL, CNT_ECAP, CNT_ELEN, CNT_ENODEV, CNT_ERANGE = 0, 1, 2, 3, 4, 5
 CNT_STRICT_LUT = 0x1
@@ -51,10 +54,14 @@ SIGNATURES = {
     "cnt_n_to_bits2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
     "cnt_bits_to_n2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
     "cnt_sharded_dev_open": (_int, [_int, _uint, ctypes.POINTER(_vp)]),
+    "cnt_sharded_dev_open_on_streams": (_int, [_int, _vp, _uint, ctypes.POINTER(_vp)]),
+    "cnt_sharded_dev_wait_event": (_int, [_vp, _int, _vp]),
+    "cnt_sharded_dev_record_event": (_int, [_vp, _int, _vp]),
     "cnt_sharded_dev_close": (_int, [_vp]),
     "cnt_sharded_dev_shards": (_int, [_vp, ctypes.POINTER(_int)]),
     "cnt_n_to_bits_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
     "cnt_bits_to_n_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
+    "cnt_round_trip_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _uint]),
     "cnt_n_to_bits2_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
     "cnt_bits_to_n2_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
     "cnt_sharded_dev_wait": (_int, [_vp, _vp]),
@@ -86,13 +93,18 @@ SIGNATURES = {
     "cnt_tuning_name": (ctypes.c_char_p, [ctypes.c_char_p, _int]),
     "cnt_chip_info": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "cnt_check_device_range": (_int, [ctypes.c_void_p, ctypes.c_size_t, _int]),
+}
+# exported by the hooks build and the lab build ONLY (include/cute_nt.h, under #ifdef CNT_TEST_HOOKS)
+TEST_HOOK_SIGNATURES = {
     "cnt_test_alias_devices": (_int, [_int]),
     "cnt_test_advise_output": (_int, [_vp, _sz]),
     "cnt_test_round_trip_plan": (_int, [_u64, _u64, _u64, _u64, _uint, ctypes.POINTER(_u64)]),
 }
+CNT_QUEUE_MAX_TIMED_OPS = 4096
 
-_libs = {}          # "product" / "lab" -> loaded CDLL
+_libs = {}          # "product" / "lab" / "hooks" -> loaded CDLL
 _active = "product"
+_PATHS = {"product": LIB_PATH, "lab": LAB_LIB_PATH, "hooks": HOOKS_LIB_PATH}
 
 
 class CuteNtError(RuntimeError):
@@ -101,13 +113,32 @@ class CuteNtError(RuntimeError):
         self.status = status
 
 
+def use_build(name):
+    """TEST / BENCH SUPPORT: make every wrapper of this package call the named build -- "product" (the default),
+    "hooks" (tests/libcute_nt_hip_hooks.so: product kernels + cnt_test_*) or "lab" (bench/libcute_nt_hip_lab.so) -- for this
+    process, until switched back.  Returns the previous name.  The builds can be loaded side by side; each keeps its own
+    streams and scratch."""
+    global _active
+    if name not in _PATHS:
+        raise ValueError("unknown build %r" % (name,))
+    prev, _active = _active, name
+    return prev
+
+
+def active_build():
+    return _active
+
+
+def has_test_hooks():
+    return _active in ("lab", "hooks")
+
+
 def use_lab_build(on=True):
     """BENCH / TEST SUPPORT: make every wrapper of this package call bench/libcute_nt_hip_lab.so (built on demand) instead of
     the product library, for this process, until switched back.  Returns the previous setting.  Both libraries can be
     loaded side by side; each keeps its own streams and scratch."""
-    global _active
     prev = _active == "lab"
-    _active = "lab" if on else "product"
+    use_build("lab" if on else "product")
     return prev
 
 
@@ -118,20 +149,20 @@ def is_lab_build():
 def lib():
     """Load the active HIP library (once per build).  Raises if it is not built -- no CPU fallback exists."""
     if _active not in _libs:
-        path = LAB_LIB_PATH if _active == "lab" else LIB_PATH
+        path = _PATHS[_active]
         if not os.path.exists(path):
             # not built yet on this box: compile it (hipcc, gfx950) rather than give up -- this is
             # still the HIP library, never a CPU substitute; without hipcc the import fails below
             try:
                 from . import build as _build
 
-                (_build.build_lab if _active == "lab" else _build.build)()
+                {"lab": _build.build_lab, "hooks": _build.build_hooks, "product": _build.build}[_active]()
             except Exception as exc:  # noqa: BLE001
                 raise ImportError("%s is missing and could not be built: %s" % (path, exc)) from exc
         if not os.path.exists(path):
             raise ImportError(
                 "%s is missing: build it with `python -m cute_nucleotides_amd.build%s` "
-                "(or __graft_entry__.build()); this package has no CPU fallback" % (path, " --lab" if _active == "lab" else "")
+                "(or __graft_entry__.build()); this package has no CPU fallback" % (path, {"lab": " --lab", "hooks": " --hooks", "product": ""}[_active])
             )
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname
         # libamdhip64.so.7) and loads it by file name, so it must be in the process BEFORE this
@@ -141,10 +172,15 @@ def lib():
 
         L = ctypes.CDLL(path)
         _assert_single_hip_runtime()
-        for name, (res, args) in SIGNATURES.items():
+        sigs = dict(SIGNATURES, **TEST_HOOK_SIGNATURES) if _active != "product" else SIGNATURES
+        for name, (res, args) in sigs.items():
             f = getattr(L, name)  # AttributeError here = ABI mismatch, fail loudly
             f.restype = res
             f.argtypes = args
+        if _active == "product":
+            for name in TEST_HOOK_SIGNATURES:  # the product exports no test hook
+                if hasattr(L, name):
+                    raise ImportError("%s exports the test hook %s: it is not a product build" % (path, name))
         if L.cnt_abi_version() != 1:
             raise ImportError("libcute_nt_hip ABI version mismatch")
         _libs[_active] = L

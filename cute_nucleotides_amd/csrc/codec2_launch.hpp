@@ -264,7 +264,9 @@ constexpr int kRoundTripDefaultPlan = 3;  // any-alignment launch plan (device_t
 // two of its 2-KiB tiles per 4-KiB unit -- kept selectable (tuning key "round_trip_shape") for A/B runs
 template <bool STRICT>
 void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, RoundTripEdges e, hipStream_t s) {
-    const uint64_t per_launch = max_tiles_per_launch(64) / 2;  // in 4-KiB units, valid for both shapes
+    // in 4-KiB units: 2^25 - 64 one-wave workgroups per launch, i.e. ONE launch up to (just under) 2^37 nt -- BASELINE.json
+    // configs[3] (2^36 nt) included; the lab's shape 1 spends two workgroups per unit
+    const uint64_t per_launch = max_tiles_per_launch(64) / (shape == 1 ? 2 : 1);
     const uint32_t lds = lds_for_cap(cap);
     const uint32_t xs = xcd_shift();
     e.tail_first = total_tiles * (kRoundTripTile / 32);
@@ -292,7 +294,7 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
 template <bool STRICT>
 void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap,
                            RoundTripEdgesAny e, hipStream_t s, int map = 0) {
-    const uint64_t per_launch = max_tiles_per_launch(64) / 2;
+    const uint64_t per_launch = max_tiles_per_launch(64);  // one workgroup per 4-KiB tile under every map: one launch up to 2^37 nt
     const uint32_t lds = std::max(lds_for_cap(cap), kRoundTripAnySlab);
     const uint32_t xs = xcd_shift();
     const uint64_t items = std::max<uint64_t>(e.p0, (e.t0 + 15) >> 4) + (e.dwords - std::min<uint64_t>(e.p1, e.t1 >> 4));

@@ -296,6 +296,15 @@ int cnt_sharded_dev_open(int ndev, unsigned flags, void** queue) {
     *queue = q;
     return rc;
 }
+int cnt_sharded_dev_open_on_streams(int ndev, void* const* streams, unsigned flags, void** queue) {
+    ShardQueue* q = nullptr;
+    if (!queue) return CNT_EINVAL;
+    const int rc = shard_queue_open(ndev, flags, &q, streams, true);
+    *queue = q;
+    return rc;
+}
+int cnt_sharded_dev_wait_event(void* queue, int k, void* event) { return shard_queue_event(queue, k, event, false); }
+int cnt_sharded_dev_record_event(void* queue, int k, void* event) { return shard_queue_event(queue, k, event, true); }
 int cnt_sharded_dev_close(void* queue) { return shard_queue_close(queue); }
 int cnt_sharded_dev_wait(void* queue, float* shard_ms) { return shard_queue_wait(queue, shard_ms); }
 int cnt_sharded_dev_shards(void* queue, int* ndev) {
@@ -306,9 +315,12 @@ int cnt_sharded_dev_shards(void* queue, int* ndev) {
 }
 int cnt_sharded_dev_op_ms(void* queue, size_t op, float* shard_ms) {
     ShardQueue* q = shard_queue_of(queue);
-    if (!q || !shard_ms || !q->timed || op >= q->last_ops) return CNT_EINVAL;
-    for (int k = 0; k < q->ndev; ++k) shard_ms[k] = q->op_ms[k][op];
-    return CNT_OK;
+    if (!q || !shard_ms) return CNT_EINVAL;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    const int rc = q->op_times(op, shard_ms);
+    (void)hipSetDevice(prev);
+    return rc;
 }
 static int queue_encode(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags,
                         int (*fn)(const void*, size_t, void*, size_t, unsigned, hipStream_t)) {
@@ -324,6 +336,11 @@ int cnt_n_to_bits_sharded_dev_enqueue(void* queue, const void* const* d_n, const
 }
 int cnt_bits_to_n_sharded_dev_enqueue(void* queue, const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, unsigned flags) {
     return queue_decode(queue, d_bits, words, len, d_out, flags, decode_dev);
+}
+int cnt_round_trip_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_bits, const size_t* out_words, void* const* d_back,
+                                       unsigned flags) {
+    if (!d_n || !n_len || !d_bits || !out_words || !d_back) return CNT_EINVAL;
+    return shard_queue_enqueue(queue, [&](int k, hipStream_t s) { return round_trip_dev(d_n[k], n_len[k], d_bits[k], out_words[k], d_back[k], flags, s); });
 }
 int cnt_n_to_bits2_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags) {
     return queue_encode(queue, d_n, n_len, d_out, out_words, flags, encode2_dev);
@@ -547,6 +564,9 @@ int cnt_check_device_range(const void* p, size_t bytes, int device) {
     return CNT_OK;
 }
 
+// ---- test hooks: compiled ONLY with -DCNT_TEST_HOOKS (tests/libcute_nt_hip_hooks.so and the lab build) -----------------------
+// The product library exports none of them and holds no switch they could flip (include/cute_nt.h, "test support").
+#ifdef CNT_TEST_HOOKS
 int cnt_test_alias_devices(int on) { return g_alias_devices.exchange(on ? 1 : 0); }
 int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t* out) {
     if (!out || (a_bits & 7) || (flags & ~kEncodeFlags)) return CNT_EINVAL;
@@ -570,6 +590,7 @@ int cnt_test_advise_output(void* out, size_t bytes) {
     advise_huge_output(out, bytes);
     return CNT_OK;
 }
+#endif  // CNT_TEST_HOOKS
 
 const char* cnt_tuning_name(const char* key, int value) {
     if (!key) return nullptr;

@@ -230,7 +230,33 @@ class ShardedDevQueue {
         detail::check(cnt_sharded_dev_open(ndev, timed ? CNT_QUEUE_TIMED : 0u, &handle_));
         detail::check(cnt_sharded_dev_shards(handle_, &ndev_));
     }
+    /// the queue ADOPTS the caller's streams (streams[k]: a non-null hipStream_t of device k): shard k's ops run in order with
+    /// whatever else the caller enqueues there; close() leaves them alone
+    explicit ShardedDevQueue(const std::vector<void*>& streams, bool timed = false) {
+        detail::check(cnt_sharded_dev_open_on_streams((int)streams.size(), streams.data(), timed ? CNT_QUEUE_TIMED : 0u, &handle_));
+        detail::check(cnt_sharded_dev_shards(handle_, &ndev_));
+    }
     ~ShardedDevQueue() { (void)cnt_sharded_dev_close(handle_); }
+    /// shard k's stream waits ON THE DEVICE for `event` (a hipEvent_t recorded behind the producer of shard k's buffer)
+    void wait_event(int k, void* event) { detail::check(cnt_sharded_dev_wait_event(handle_, k, event)); }
+    /// records the caller's hipEvent_t (of shard k's device) behind everything queued for shard k so far
+    void record_event(int k, void* event) { detail::check(cnt_sharded_dev_record_event(handle_, k, event)); }
+    /// the fused encode + decode of cnt_round_trip_dev on every shard
+    void enqueue_round_trip(const std::vector<const DeviceBuffer*>& n, const std::vector<size_t>& n_len, const std::vector<DeviceBuffer*>& bits,
+                            const std::vector<DeviceBuffer*>& back, bool strict_lut = false) {
+        if ((int)n.size() != ndev_ || (int)n_len.size() != ndev_ || (int)bits.size() != ndev_ || (int)back.size() != ndev_) throw std::invalid_argument("one entry per shard");
+        std::vector<const void*> in(n.size());
+        std::vector<void*> o(n.size()), b(n.size());
+        std::vector<size_t> cap(n.size());
+        for (size_t k = 0; k < n.size(); ++k) {
+            if (n_len[k] > n[k]->size_bytes() || n_len[k] > back[k]->size_bytes()) throw std::out_of_range("enqueue_round_trip: n_len");
+            in[k] = n[k]->data();
+            o[k] = bits[k]->data();
+            b[k] = back[k]->data();
+            cap[k] = bits[k]->size_bytes() / 8;
+        }
+        detail::check(cnt_round_trip_sharded_dev_enqueue(handle_, in.data(), n_len.data(), o.data(), cap.data(), b.data(), strict_lut ? CNT_STRICT_LUT : 0u));
+    }
     ShardedDevQueue(const ShardedDevQueue&) = delete;
     ShardedDevQueue& operator=(const ShardedDevQueue&) = delete;
     int shards() const { return ndev_; }

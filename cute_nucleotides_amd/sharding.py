@@ -59,9 +59,14 @@ def alias_devices(on):
     """TEST SUPPORT (cnt_test_alias_devices): let the sharded tiers fold ndev > visible devices onto the devices that
     exist (shard k -> device k % count).  Returns the previous setting.  Off by default; there is no environment
     variable for it."""
-    from ._lib import lib
+    from . import _lib
 
-    return bool(lib().cnt_test_alias_devices(1 if on else 0))
+    if not _lib.has_test_hooks():
+        if not on:
+            return False  # the product has no such switch: shard k runs on device k, always
+        raise RuntimeError("alias_devices is test support that the product library does not contain: switch to the test-hooks "
+                           "build first (_lib.use_build('hooks'); tests: the `hooks_build` fixture)")
+    return bool(_lib.lib().cnt_test_alias_devices(1 if on else 0))
 
 
 def _check_placement(shards, outs, extra=None):
@@ -183,10 +188,20 @@ class DevQueue:
             ms = q.wait()                               # per-shard device milliseconds of the whole batch
             enc0 = q.op_ms(0)                           # ... and of each op
 
-    The tensors handed to an enqueue call are kept alive until the next wait(); whatever produced them on torch's streams
-    must be complete before the call (the queue's streams are the library's own)."""
+    The tensors handed to an enqueue call are kept alive until the next wait().  The queue's streams are the library's
+    own: whatever produced a shard on a torch stream must either be complete before the ops that read it are enqueued, or
+    -- no host synchronisation -- be ordered in front of them ON THE DEVICE:
 
-    def __init__(self, ndev=0, timed=False):
+        ev = torch.cuda.Event(); ev.record(producer_stream_k)   # behind the kernel that fills shard k
+        q.wait_event(k, ev)                                     # shard k's stream waits for it (hipStreamWaitEvent)
+        q.n_to_bits(...)                                        # runs behind the producer, the host never stopped
+        done = torch.cuda.Event(); q.record_event(k, done)      # completes when shard k's queued ops have
+        consumer_stream_k.wait_event(done)                      # a torch stream reads the outputs behind them
+
+    or hand the queue the caller's streams (`DevQueue(streams=[torch.cuda.Stream(k) ...])`, cnt_sharded_dev_open_on_streams):
+    shard k's ops are then enqueued on streams[k], in order with everything else the caller puts there."""
+
+    def __init__(self, ndev=0, timed=False, streams=None):
         import ctypes
 
         from . import _lib
@@ -194,7 +209,18 @@ class DevQueue:
 
         self._L = lib()
         self._h = ctypes.c_void_p()
-        check(self._L.cnt_sharded_dev_open(ndev, _lib.CNT_QUEUE_TIMED if timed else 0, ctypes.byref(self._h)))
+        flags = _lib.CNT_QUEUE_TIMED if timed else 0
+        self._streams = None
+        if streams is not None:
+            if ndev not in (0, len(streams)):
+                raise ValueError("ndev = %d but %d streams" % (ndev, len(streams)))
+            handles = [getattr(st, "cuda_stream", st) for st in streams]  # torch.cuda.Stream or a raw hipStream_t
+            if any(not h for h in handles):
+                raise ValueError("a queue never adopts the legacy default stream (handle 0)")
+            self._streams = list(streams)  # the caller's streams outlive the queue
+            check(self._L.cnt_sharded_dev_open_on_streams(len(handles), _ptr_array(handles), flags, ctypes.byref(self._h)))
+        else:
+            check(self._L.cnt_sharded_dev_open(ndev, flags, ctypes.byref(self._h)))
         n = ctypes.c_int(0)
         check(self._L.cnt_sharded_dev_shards(self._h, ctypes.byref(n)))
         self.ndev, self.timed, self._keep, self.ops = n.value, timed, [], 0
@@ -274,6 +300,64 @@ class DevQueue:
         check(fn(self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
                  _size_array(list(lengths)), _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), 0))
         self.ops += 1
+
+    def round_trip(self, shards, out_bits, out_n, strict_lut=False, tail_lut=False):
+        """queue one FUSED encode + decode of every shard (cnt_round_trip_sharded_dev_enqueue): out_bits[k] = n_to_bits(shards[k]),
+        out_n[k] = its decoded canonical spelling"""
+        import torch
+
+        from ._lib import check
+        from .n_to_bits import encode_flags
+
+        self._own(shards)
+        if len(out_bits) != len(shards) or len(out_n) != len(shards):
+            raise ValueError("shards, out_bits and out_n must have one entry per shard")
+        for t, o, b in zip(shards, out_bits, out_n):
+            if not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+                raise ValueError("shards must be contiguous uint8 CUDA tensors")
+            if o.dtype != torch.int64 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < self._L.cnt_words_for(t.numel()):
+                raise ValueError("out_bits[k] must be a contiguous int64 CUDA tensor on shard k's device with >= words elements")
+            if b.dtype != torch.uint8 or not b.is_cuda or not b.is_contiguous() or b.device != t.device or b.numel() < t.numel():
+                raise ValueError("out_n[k] must be a contiguous uint8 CUDA tensor on shard k's device with >= n_len elements")
+        _check_placement(shards, out_bits)
+        self._keep.append((shards, out_bits, out_n))
+        check(self._L.cnt_round_trip_sharded_dev_enqueue(
+            self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+            _ptr_array([o.data_ptr() if o.numel() else 0 for o in out_bits]), _size_array([o.numel() for o in out_bits]),
+            _ptr_array([b.data_ptr() if b.numel() else 0 for b in out_n]), encode_flags(strict_lut, tail_lut)))
+        self.ops += 1
+
+    @staticmethod
+    def _event_handle(event):
+        h = getattr(event, "cuda_event", event)  # torch.cuda.Event (created lazily: it must have been recorded / be recordable) or a raw hipEvent_t
+        if not h:
+            raise ValueError("the event has no HIP handle yet: record it (torch creates events lazily) or pass a raw hipEvent_t")
+        return h
+
+    def wait_event(self, k, event):
+        """shard k's stream waits ON THE DEVICE for `event` (a recorded torch.cuda.Event or raw hipEvent_t): everything
+        enqueued for shard k afterwards runs behind whatever the event covers.  The host does not wait."""
+        import ctypes
+
+        from ._lib import check
+
+        if self._h is None:
+            raise ValueError("queue is closed")
+        self._keep.append((event,))
+        check(self._L.cnt_sharded_dev_wait_event(self._h, k, ctypes.c_void_p(self._event_handle(event))))
+
+    def record_event(self, k, event):
+        """record `event` (created on shard k's device) on shard k's stream: it completes when everything enqueued for shard k
+        so far has; a consumer stream that waits on it needs no host synchronisation.  A torch.cuda.Event must already own
+        a HIP event (torch creates it on first record): record it once on any stream of that device first."""
+        import ctypes
+
+        from ._lib import check
+
+        if self._h is None:
+            raise ValueError("queue is closed")
+        self._keep.append((event,))
+        check(self._L.cnt_sharded_dev_record_event(self._h, k, ctypes.c_void_p(self._event_handle(event))))
 
     def wait(self):
         """drain every shard's stream; returns the per-shard device milliseconds of the batch (zeros unless timed)"""

@@ -118,8 +118,7 @@ int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out)
  * Each worker (and the copy threads it owns) is pinned to the CPUs of its GPU's
  * NUMA node; CNT_SHARD_NUMA=0 disables that, CNT_SHARD_COPY_THREADS_TOTAL
  * (default 32) bounds the staging-copy threads summed over all devices.
- * ndev > visible devices is CNT_ENODEV (but see cnt_test_alias_devices at the end of
- * this header).  The _ex forms take the encode flags. */
+ * ndev > visible devices is CNT_ENODEV.  The _ex forms take the encode flags. */
 int cnt_n_to_bits_sharded(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev);
 int cnt_n_to_bits_sharded_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, int ndev, unsigned flags);
 int cnt_bits_to_n_sharded(const uint64_t *bits, size_t words, size_t len, uint8_t *out, int ndev);
@@ -141,7 +140,7 @@ int cnt_shard_worker_info(int k, int *device, int *numa_node, int *n_cpus, int *
 
 /* ---- multi-GPU device tier: shards already resident, one per device ---------------- */
 /* Arrays of ndev entries; shard k is device memory ON DEVICE k (ndev <= 0: all visible
- * devices; under cnt_test_alias_devices: device k % count).  The calling thread enqueues every
+ * devices).  The calling thread enqueues every
  * shard on a library-owned stream of its own (on that shard's device) -- the devices then run concurrently -- and
  * returns when all have finished: no host staging, no collective, no helper threads.  The streams
  * are the library's own (non-blocking), so whatever produced the shards must be COMPLETE before the
@@ -171,16 +170,45 @@ int cnt_bits_to_n2_sharded_dev(const void *const *d_bits, const size_t *words, c
  *                           counted; shards already queued still run and the next wait drains them.
  *   cnt_sharded_dev_wait    returns when every shard's stream is idle.  shard_ms (optional, ndev floats; zeros unless
  *                           CNT_QUEUE_TIMED): each shard's device time over the whole batch since the previous wait.
- *   cnt_sharded_dev_op_ms   CNT_QUEUE_TIMED: per-shard device time of op `op` (0-based) of the batch the last wait drained.
+ *   cnt_sharded_dev_op_ms   CNT_QUEUE_TIMED: per-shard device time of op `op` (0-based) of the batch the last wait drained;
+ *                           readable until the next enqueue on the queue (which re-records the batch's events).
  *   cnt_sharded_dev_close   waits, then frees the streams and events.
  * A queue is used by one thread at a time; different queues are independent.  The calling thread's current device is
- * restored by every call.  An unknown / closed handle is CNT_EINVAL. */
+ * restored by every call.  An unknown / closed handle is CNT_EINVAL.  A CNT_QUEUE_TIMED queue holds at most
+ * CNT_QUEUE_MAX_TIMED_OPS ops per batch (one event per op and shard, recycled by the next batch): the enqueue past that is
+ * CNT_ECAP and queues nothing -- wait first; an untimed queue keeps no per-op state and has no limit.
+ *
+ * ORDERING A QUEUE AGAINST THE CALLER'S OWN WORK WITHOUT STOPPING THE HOST (generator -> encode -> consumer on N devices):
+ *   cnt_sharded_dev_wait_event    shard k's stream waits ON THE DEVICE (hipStreamWaitEvent) for `event`, a hipEvent_t the
+ *                                 caller recorded on the stream that produces shard k's buffer; everything enqueued for
+ *                                 shard k after this call runs behind it.  The producer need not have finished -- or even
+ *                                 started -- when the ops are enqueued: the "whatever produced them must be complete"
+ *                                 clause above does not apply to a shard ordered this way.
+ *   cnt_sharded_dev_record_event  records the caller's hipEvent_t (created on shard k's device) on shard k's stream: it
+ *                                 completes when everything enqueued for shard k so far has.  A consumer stream that
+ *                                 hipStreamWaitEvent()s on it reads the outputs without any host synchronisation.
+ *   cnt_sharded_dev_open_on_streams  the queue ADOPTS the caller's streams instead of creating its own: streams[k] is a
+ *                                 hipStream_t of device k (never NULL: the legacy default stream synchronises with
+ *                                 everything), shard k's ops are enqueued on it, in order with whatever the caller puts
+ *                                 on that stream before and after -- the ordering the single-GPU *_dev entry points have
+ *                                 by taking the caller's stream.  close() neither synchronises nor destroys adopted
+ *                                 streams; wait() synchronises them.
+ * With CNT_QUEUE_TIMED the time a shard's stream spends waiting for a caller event counts into the op enqueued after it,
+ * unless that op is the first of its batch (the batch's start event is recorded behind the wait). */
 #define CNT_QUEUE_TIMED 0x1u
+#define CNT_QUEUE_MAX_TIMED_OPS 4096
 int cnt_sharded_dev_open(int ndev, unsigned flags, void **queue);
+int cnt_sharded_dev_open_on_streams(int ndev, void *const *streams, unsigned flags, void **queue);
+int cnt_sharded_dev_wait_event(void *queue, int k, void *event);
+int cnt_sharded_dev_record_event(void *queue, int k, void *event);
 int cnt_sharded_dev_close(void *queue);
 int cnt_sharded_dev_shards(void *queue, int *ndev);
 int cnt_n_to_bits_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags);
 int cnt_bits_to_n_sharded_dev_enqueue(void *queue, const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out, unsigned flags);
+/* the fused encode + decode of cnt_round_trip_dev (BASELINE.json configs[3]) on every shard: d_bits[k] = n_to_bits(d_n[k]),
+ * d_back[k] = its decoded, canonical spelling; per-shard contract as cnt_round_trip_dev */
+int cnt_round_trip_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_bits, const size_t *out_words,
+                                       void *const *d_back, unsigned flags);
 int cnt_n_to_bits2_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags);
 int cnt_bits_to_n2_sharded_dev_enqueue(void *queue, const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out, unsigned flags);
 int cnt_sharded_dev_wait(void *queue, float *shard_ms);
@@ -189,7 +217,11 @@ int cnt_sharded_dev_op_ms(void *queue, size_t op, float *shard_ms);
 /* ---- device-pointer tier: what the roofline metric measures ------------------- */
 /* Pointers are device memory on the calling thread's current device.  `stream`
  * is a hipStream_t (NULL = the legacy default stream); the call only enqueues
- * (no synchronisation, no allocation: it can be captured into a HIP graph).
+ * (no synchronisation, no allocation: it can be captured into a HIP graph) -- ONE kernel launch per call while the
+ * call's tiles fit HIP's 2^31-1 threads per launch, i.e. 2^25-64 one-wave tiles: below 2^36 nt for the 2-bit encoder
+ * (2-KiB tiles), 2^37 nt for the decoder and the fused call (4-KiB tiles; BASELINE.json configs[3], 2^36 nt, is one
+ * launch), 1.69 x 2^36 nt for the 5-letter codec (3456-nt tiles); ceil(tiles / (2^25-64)) launches beyond, the ragged
+ * edges always in the last one.
  * ASCII pointers may have ANY alignment, word pointers 8 bytes; all combinations
  * run within a few percent of the aligned speed (a short head is peeled so the
  * stores are line-aligned, the loads absorb the phase), both codecs.
@@ -202,7 +234,7 @@ int cnt_n_to_bits2_dev(const void *d_n, size_t n_len, void *d_out, size_t out_wo
  * d_back = bits_to_n(d_bits, n_len) -- i.e. the canonical spelling of the input: upper case,
  * U -> T, and with CNT_STRICT_LUT every byte outside the alphabet -> 'A' (n_to_bits.rs:8-21
  * followed by :23-30) -- reading the ASCII once and never re-reading the packed words (2.25
- * instead of 2.5 bytes of HBM traffic per nucleotide).  d_back holds n_len bytes.  ONE launch at any size and any
+ * instead of 2.5 bytes of HBM traffic per nucleotide).  d_back holds n_len bytes.  One launch (up to 2^37 nt) at any
  * alignment of d_n and d_back (d_bits: 8 bytes, as everywhere): off the 128-byte grid the tiles are laid on the decoded
  * stream's lines and the other two streams' phases are resolved on the packed codes (within a few percent of the
  * aligned speed). */
@@ -316,12 +348,19 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy teams summed over all devices (default 32: 8 shards -> teams of
  *                                4); as above the threads that exist are up to twice that minus one per shard */
 
-/* ---- test support ------------------------------------------------------------------
+/* ---- test support: NOT part of libcute_nt_hip.so ----------------------------------------
+ * The product library neither exports these three nor contains the state they touch (tests/test_abi.py checks its dynamic
+ * symbol table): like the reference's functions over immutable tables (n_to_bits.rs:8,23) it has no process-global switch.
+ * The same translation unit compiled with -DCNT_TEST_HOOKS is tests/libcute_nt_hip_hooks.so (cute_nucleotides_amd/build.py
+ * build_hooks; the lab build has the hooks too) -- every kernel byte-identical to the product's
+ * (tests/test_isa_digest.py) -- and is what the N > 1 sharded tests, test_hugepage_scope and test_round_trip_plan load.
+ *
  * cnt_test_alias_devices(1) lets the sharded tiers accept ndev > visible devices (<= 64) and run
  * shard k on device k % count, so that the ndev > 1 arithmetic (partition, empty and ragged shards,
  * per-shard streams) can be exercised on a 1-GPU box.  OFF by default and reachable only through this
- * call -- no environment variable can make a production process shard onto the wrong device.
+ * call -- no environment variable can make a process shard onto the wrong device.
  * Returns the previous setting. */
+#ifdef CNT_TEST_HOOKS
 int cnt_test_alias_devices(int on);
 /* Runs the host tier's huge-page advice (see CNT_HOST_HUGEPAGE above) on [out, out + bytes) exactly as a host-tier call
  * with that output would, without any device work: lets a box without a GPU check what the library does -- and does not
@@ -335,6 +374,7 @@ int cnt_test_advise_output(void *out, size_t bytes);
  * the slab, every letter and packed dword owned by exactly one of tiles / edge items, tiles off the final partial word
  * under CNT_TAIL_LUT. */
 int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t *out);
+#endif /* CNT_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

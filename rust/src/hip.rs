@@ -38,6 +38,10 @@ extern "C" {
     fn cnt_shutdown() -> c_int;
     // multi-GPU device tier, enqueue-only: one library stream per shard, any number of ops queued ahead, one wait
     fn cnt_sharded_dev_open(ndev: c_int, flags: c_uint, queue: *mut *mut c_void) -> c_int;
+    fn cnt_sharded_dev_open_on_streams(ndev: c_int, streams: *const *mut c_void, flags: c_uint, queue: *mut *mut c_void) -> c_int;
+    fn cnt_sharded_dev_shards(queue: *mut c_void, ndev: *mut c_int) -> c_int;
+    fn cnt_sharded_dev_wait_event(queue: *mut c_void, k: c_int, event: *mut c_void) -> c_int;
+    fn cnt_sharded_dev_record_event(queue: *mut c_void, k: c_int, event: *mut c_void) -> c_int;
     fn cnt_sharded_dev_close(queue: *mut c_void) -> c_int;
     fn cnt_n_to_bits_sharded_dev_enqueue(queue: *mut c_void, d_n: *const *const c_void, n_len: *const usize, d_out: *const *mut c_void, out_words: *const usize, flags: c_uint) -> c_int;
     fn cnt_bits_to_n_sharded_dev_enqueue(queue: *mut c_void, d_bits: *const *const c_void, words: *const usize, len: *const usize, d_out: *const *mut c_void, flags: c_uint) -> c_int;
@@ -366,11 +370,48 @@ pub struct ShardedDevQueue {
 }
 
 impl ShardedDevQueue {
-    /// `ndev` shards on devices `0..ndev`; `timed` records an event behind every op (`wait` / `op_ms` report device ms).
+    /// `ndev` shards on devices `0..ndev` (`0` = all visible devices); `timed` records an event behind every op
+    /// (`wait` / `op_ms` report device ms; at most 4096 ops per batch).  `self.ndev` is the shard count the LIBRARY
+    /// resolved (`cnt_sharded_dev_shards`), never the caller's `0`: `wait` / `op_ms` size their buffers by it.
     pub fn new(ndev: usize, timed: bool) -> ShardedDevQueue {
+        assert!(ndev <= c_int::MAX as usize);
         let mut handle: *mut c_void = std::ptr::null_mut();
         unsafe { check(cnt_sharded_dev_open(ndev as c_int, if timed { CNT_QUEUE_TIMED } else { 0 }, &mut handle)) };
-        ShardedDevQueue { handle, ndev }
+        ShardedDevQueue::adopt(handle)
+    }
+
+    /// The queue adopts the caller's streams (`streams[k]`: a non-null `hipStream_t` of device `k`): shard `k`'s ops run in
+    /// order with whatever else the caller enqueues there -- no host synchronisation between producer, codec and consumer.
+    pub fn on_streams(streams: &[*mut c_void], timed: bool) -> ShardedDevQueue {
+        assert!(!streams.is_empty() && streams.len() <= c_int::MAX as usize && streams.iter().all(|s| !s.is_null()));
+        let mut handle: *mut c_void = std::ptr::null_mut();
+        unsafe { check(cnt_sharded_dev_open_on_streams(streams.len() as c_int, streams.as_ptr(), if timed { CNT_QUEUE_TIMED } else { 0 }, &mut handle)) };
+        ShardedDevQueue::adopt(handle)
+    }
+
+    fn adopt(handle: *mut c_void) -> ShardedDevQueue {
+        let mut n: c_int = 0;
+        unsafe { check(cnt_sharded_dev_shards(handle, &mut n)) };
+        assert!(n >= 1);
+        ShardedDevQueue { handle, ndev: n as usize }
+    }
+
+    /// Number of shards this queue drives.
+    pub fn shards(&self) -> usize {
+        self.ndev
+    }
+
+    /// Shard `k`'s stream waits ON THE DEVICE for `event` (a `hipEvent_t` the caller recorded behind the work that
+    /// produces shard `k`'s buffer); ops enqueued afterwards run behind it.  The host does not wait.
+    pub fn wait_event(&mut self, k: usize, event: *mut c_void) {
+        assert!(k < self.ndev && !event.is_null());
+        unsafe { check(cnt_sharded_dev_wait_event(self.handle, k as c_int, event)) };
+    }
+
+    /// Record the caller's `hipEvent_t` (of shard `k`'s device) behind everything queued for shard `k` so far.
+    pub fn record_event(&mut self, k: usize, event: *mut c_void) {
+        assert!(k < self.ndev && !event.is_null());
+        unsafe { check(cnt_sharded_dev_record_event(self.handle, k as c_int, event)) };
     }
 
     /// Queue the encode of every shard: `d_n[k]` holds `n_len[k]` nucleotides on device `k`, `d_out[k]` its words.

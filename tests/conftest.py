@@ -41,6 +41,22 @@ def lab_build():
     _lib.use_lab_build(prev)
 
 
+@pytest.fixture()
+def hooks_build():
+    """Run this test against tests/libcute_nt_hip_hooks.so (-DCNT_TEST_HOOKS: the product's sources and kernels plus the three
+    cnt_test_* hooks).  The product library exports no hook and has no switch that could fold shards onto another device
+    (VERDICT r04 next-4), so every test that needs N > 1 shards on the 1-GPU box, the huge-page advice alone or the fused
+    launch plan takes this fixture; everything else runs on the product."""
+    from cute_nucleotides_amd import _lib
+
+    prev = _lib.use_build("hooks")
+    L = _lib.lib()
+    assert L.cnt_test_alias_devices(0) == 0  # really the hooks build, and the switch is off
+    yield L
+    L.cnt_test_alias_devices(0)
+    _lib.use_build(prev)
+
+
 @pytest.fixture(scope="session")
 def kats():
     import json

@@ -21,10 +21,20 @@ def L():
     return _lib.lib()
 
 
-def _declared():
+def _declared(hooks=False):
+    """symbols include/cute_nt.h declares: outside its #ifdef CNT_TEST_HOOKS section (the product's ABI), or inside it"""
     text = open(os.path.join(ROOT, "include", "cute_nt.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cnt_\w+)\s*\(", text)))
+    inside = "".join(re.findall(r"#ifdef CNT_TEST_HOOKS(.*?)#endif", text, flags=re.S))
+    outside = re.sub(r"#ifdef CNT_TEST_HOOKS.*?#endif", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnt_\w+)\s*\(", inside if hooks else outside)))
+
+
+def _exported(path):
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("cnt_")})
 
 
 def test_every_declared_symbol_is_exported_and_bound(L):
@@ -36,6 +46,23 @@ def test_every_declared_symbol_is_exported_and_bound(L):
         assert hasattr(L, name), "header declares %s but the library does not export it" % name
         assert name in _lib.SIGNATURES, "%s not bound in _lib.SIGNATURES" % name
     assert sorted(_lib.SIGNATURES) == names
+    assert _exported(_lib.LIB_PATH) == names  # ... and the library exports nothing the header does not declare
+
+
+def test_product_exports_no_test_hook():
+    """cnt_test_alias_devices / cnt_test_advise_output / cnt_test_round_trip_plan are declared under
+    #ifdef CNT_TEST_HOOKS and exist only in tests/libcute_nt_hip_hooks.so (and the lab build): the product's dynamic symbol
+    table has no cnt_test_* entry, and the hooks build adds exactly those three to the product's ABI."""
+    from cute_nucleotides_amd import _lib, build
+
+    hooks = _declared(hooks=True)
+    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) == ["cnt_test_advise_output", "cnt_test_alias_devices", "cnt_test_round_trip_plan"]
+    product = _exported(build.build())
+    assert not [n for n in product if n.startswith("cnt_test_")], product
+    assert _exported(build.build_hooks()) == sorted(product + hooks)
+    text = open(os.path.join(ROOT, "include", "cute_nt.h")).read()
+    assert "CNT_TEST_HOOKS" not in open(os.path.join(ROOT, "tests", "c_link_check.c")).read()  # a C caller of the product never sees them
+    assert text.count("#ifdef CNT_TEST_HOOKS") == 1
 
 
 def test_product_never_imports_oracle():

@@ -104,3 +104,83 @@ def test_host_placement_reads_this_process():
         assert sum(p["pages_per_node"].values()) * 4096 >= a.nbytes // 2 and 0.0 <= p["huge_page_share"] <= 1.0
         assert p["caller_cpu"] >= 0
     assert bench.gpu_numa_node("0000:ff:1f.7") is None and bench.gpu_numa_node(None) is None  # no such device: no answer, no exception
+
+
+def _fake_rows(n, chip=None, dup=None):
+    rows = []
+    for k in range(n):
+        rows.append({"rank": k, "device_index": k, "pci_bus_id": "0000:%02x:00.0" % (0x05 + 0x10 * k), "numa_node": k // 4,
+                     "uuid": "GPU-%032x" % (0xABC0 + k), "name": "AMD Instinct MI355X", "hbm_GiB": 287.98,
+                     "chip": dict(chip or {"compute_units": 256, "lds_bytes_per_cu": 163840, "xcds": 8})})
+    if dup is not None:
+        rows[dup[1]]["uuid"], rows[dup[1]]["pci_bus_id"] = rows[dup[0]]["uuid"], rows[dup[0]]["pci_bus_id"]
+    return rows
+
+
+def test_first_contact_checklist_on_a_fake_eight_device_node():
+    """no N > 1 path has met two real devices, so the first hardware line must diagnose itself.
+    Fed an identity table of 8 visible devices (what device_row() builds from the C ABI), the `devices` block counts 8
+    distinct ones over two NUMA nodes; a table in which two ranks sit on ONE device is refused unless the fold-onto-one-GPU
+    test hook is on (then it is printed, labelled); a partitioned-mode device (fewer CUs / XCDs than an SPX MI355X) is
+    named on the line; a short row list is refused."""
+    import bench_measure as bm
+
+    d = bm.first_contact_devices(_fake_rows(8), 8, False, visible=8, processes=1, control_plane=None)
+    assert d["distinct"] == 8 and d["expected_distinct"] == 8 and d["shared_gpu_test_hook"] is False and d["numa_nodes"] == [0, 1]
+    assert d["not_an_spx_mi355x"] == [] and d["data_path_collective"] is None and d["visible"] == 8 and d["processes"] == 1
+    with pytest.raises(SystemExit, match="refusing to print a folded run as an 8-GPU line"):
+        bm.first_contact_devices(_fake_rows(8, dup=(2, 5)), 8, False)
+    d = bm.first_contact_devices(_fake_rows(8, dup=(2, 5)), 8, True)  # the test hook is on: printed, and says so
+    assert d["distinct"] == 7 and d["shared_gpu_test_hook"] is True
+    cpx = {"compute_units": 32, "lds_bytes_per_cu": 163840, "xcds": 1}
+    d = bm.first_contact_devices(_fake_rows(8, chip=cpx), 8, False)
+    assert len(d["not_an_spx_mi355x"]) == 8 and d["not_an_spx_mi355x"][3] == {"rank": 3, "pci_bus_id": "0000:35:00.0", "chip": cpx}
+    with pytest.raises(SystemExit, match="7 report rows for 8 GPUs"):
+        bm.first_contact_devices(_fake_rows(7), 8, False)
+    # rows without a UUID fall back to the PCI address
+    rows = _fake_rows(4)
+    for r in rows:
+        r["uuid"] = None
+    assert bm.first_contact_devices(rows, 4, False)["distinct"] == 4
+
+
+def test_free_hbm_check_fails_before_anything_is_allocated():
+    import bench_measure as bm
+
+    class FakeCuda:
+        @staticmethod
+        def mem_get_info(index):
+            return ((200 << 30), (288 << 30)) if index == 0 else ((20 << 30), (288 << 30))  # device 1: another tenant holds it
+
+    class FakeTorch:
+        cuda = FakeCuda
+
+    assert bm.require_free_hbm(FakeTorch, 0, 37 << 30, "the timed buffers") == {"free_GiB": 200.0, "total_GiB": 288.0}
+    with pytest.raises(SystemExit, match="device 1 has 20.0 of 288.0 GiB of HBM free, the timed buffers needs 37.0 GiB"):
+        bm.require_free_hbm(FakeTorch, 1, 37 << 30, "the timed buffers")
+
+
+def test_static_traffic_is_labelled_as_an_n1_measurement_on_an_n_gpu_line():
+    """the N > 1 lines quote profiles/hbm_traffic.json only under a label that says where it came from"""
+    import bench_measure as bm
+
+    t, src, live = bm.traffic_for_line(34, 8, allow_live=False)
+    assert live is None and t["encode_bytes_per_launch"] > 0 and t["decode_bytes_per_launch"] > 0
+    assert src.startswith("static, N = 1 measurement quoted on an N = 8 line: profiles/hbm_traffic.json") and "NOT measured by this run" in src
+    t1, src1, _ = bm.traffic_for_line(34, 1, allow_live=False)
+    assert src1.startswith("static: profiles/hbm_traffic.json") and t1 == t
+    assert abs(t["encode_bytes_per_launch"] / (1.25 * 2**34) - 1) < 1e-3
+    assert bm.traffic_for_line(26, 8, allow_live=False) == (None, None, None)  # the committed figure is for 2^34 nt only
+
+
+def test_cpu_baseline_leg_for_the_n_gpu_lines(oracle):
+    """bench.py's CPU leg as the N > 1 lines call it (faithful_tables=False): the all-core and one-thread figures of the AVX2
+    ports, cores stated, without the reference-harness tables (those stay on the N = 1 line).  Runs here: it needs no GPU."""
+    import bench
+
+    if not oracle.port_cpu_ok():
+        pytest.skip("host CPU lacks AVX2/BMI2")
+    c = bench.cpu_baseline(1.0, faithful_tables=False)
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "Gnt/s" and c["one_thread"]["value"] > 0
+    assert "reference_faithful_40k_GiBs" not in c and "N = 1 line" in c["reference_faithful_tables"]
+    assert c["cores_detail"]["threads_timed"] == c["cores"] and "sample" in c

@@ -87,14 +87,24 @@ def test_both_bench_forms_folded_onto_one_gpu(n):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, CNT_BENCH_SHARE_GPU="1")
-    common = ["--gpus", str(n), "--steps", "20", "--warmup", "2", "--log2-nt", "26", "--shard-log2-nt", "27", "--cpu-seconds", "0"]
+    # every N > 1 line is a full contract line -- `cpu_baseline` (the CPU leg runs in one of the two forms per
+    # N here, 1 s of it: the single-process form at N = 4, the rank form at N = 8) and a non-null, labelled `roofline.traffic`
+    cpu_single, cpu_ranks = ("1", "0") if n == 4 else ("0", "1")
+    common = ["--gpus", str(n), "--steps", "20", "--warmup", "2", "--log2-nt", "26", "--shard-log2-nt", "27", "--cpu-seconds", cpu_ranks]
     # (a) one process, N shards, everything queued, one wait (100 steps: the overhead figure multiplies a one-shard wall time by N)
-    single = ["--gpus", str(n), "--steps", "100", "--warmup", "5", "--log2-nt", "26", "--shard-log2-nt", "27", "--cpu-seconds", "0"]
+    single = ["--gpus", str(n), "--steps", "100", "--warmup", "5", "--log2-nt", "26", "--shard-log2-nt", "27", "--cpu-seconds", cpu_single]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + single, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     j = _last_json(out.stdout)
     assert j["n_gpus"] == n and j["verified"] is True and len(j["ranks"]) == n and j["devices"]["processes"] == 1
-    assert "enqueue-only" in j["config"]["launch"] and "ONE cnt_sharded_dev_wait" in j["config"]["launch"]
+    assert "enqueue-only" in j["config"]["launch"] and "ONE cnt_sharded_dev_wait" in j["config"]["launch"] and "cnt_sharded_dev_wait_event" in j["config"]["launch"]
+    _full_contract_line(j, n, cpu_single == "1")
+    d = j["devices"]  # first contact (next-5): N shards folded onto this box's one device -- printed, and labelled as folded
+    assert d["distinct"] == 1 and d["expected_distinct"] == n and d["shared_gpu_test_hook"] is True and d["library_build"] == "hooks" and d["visible"] == 1
+    assert all(r["chip"] == j["ranks"][0]["chip"] and r["chip"]["compute_units"] > 0 and r["chip"]["xcds"] >= 1 and r["hbm_before"]["free_GiB"] > 1 for r in j["ranks"])
+    f = j["fused_round_trip"]  # the fused pass of every shard through the same queue, verified against the two-pass outputs
+    assert f["ms_stats"]["verified"] is True and 0 < f["frac_over_ranks"]["min"] <= f["frac_over_ranks"]["max"] < 1.2 and f["bytes_per_nt"] == 2.25
+    assert 1000.0 < j["ceilings"]["rank0"]["read_only"]["GBs"] < 8000.0 and j["ceilings"]["encode_vs"]["of_read4_write1_ceiling"] > 0.3
     so = j["scaling_overhead"]
     assert so["shards_per_device"] == n and so["per_step_us"] == j["scaling_overhead_us"]
     assert so["per_step_us"] <= 31.0, so  # 1 % of a 3.1-ms kernel; folded shards overlap, so the number is usually negative
@@ -111,6 +121,30 @@ def test_both_bench_forms_folded_onto_one_gpu(n):
     assert j["n_gpus"] == n and j["verified"] is True and [r["rank"] for r in j["ranks"]] == list(range(n))
     assert len({r["pid"] for r in j["ranks"]}) == n and j["devices"]["control_plane"] == "gloo"
     assert j["config"]["nt_per_step"] == 2 * n * (1 << 26) and j["configs4_sharded_encode"]["ranks_measured"] == n
+    _full_contract_line(j, n, cpu_ranks == "1")
+    assert j["devices"]["distinct"] == 1 and j["devices"]["expected_distinct"] == n and j["devices"]["shared_gpu_test_hook"] is True
+    assert all(r["chip"]["compute_units"] > 0 and r["hbm_before"]["free_GiB"] > 1 for r in j["ranks"])
+
+
+def _full_contract_line(j, n, with_cpu):
+    """what a SCALE line must carry at N > 1 (VERDICT r04 missing-1): the contract keys, both rooflines with a non-null traffic and
+    a source that says how it was obtained, and -- when the CPU leg ran -- cpu_baseline with value, unit, cores, kind, sample"""
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in j, key
+    assert j["scaling"] == "weak" and j["dtype"] == "u8" and j["vs_baseline"] is None and "workload" in j["config"]
+    for key in ("roofline", "roofline_decode"):
+        r = j[key]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["traffic"] is not None and r["traffic"] > 0, (key, j.get("traffic_live"))
+        assert r["traffic_source"].startswith(("measured by this run", "static")), r["traffic_source"]
+        if r["traffic_source"].startswith("measured"):  # 2^26-nt launches: the calibrated counters land within a few percent
+            assert "rank 0's device" in r["traffic_source"] and abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1.0) < 0.05, (key, r["traffic"])
+    if with_cpu:
+        c = j["cpu_baseline"]
+        assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "Gnt/s" and c["sample"] and "after the timed region" in c["when"]
+        assert c["encode_gnts"] > 0 and c["decode_gnts"] > 0 and c["one_thread"]["value"] > 0
+    else:
+        assert "cpu_baseline" not in j  # --cpu-seconds 0
 
 
 def test_two_rank_launch_path_shares_one_gpu():
@@ -126,7 +160,7 @@ def test_two_rank_launch_path_shares_one_gpu():
     j = _last_json(out.stdout)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified"] is True
     assert j["config"]["nt_per_gpu"] == 1 << 28 and j["config"]["nt_per_step"] == 2 * 2 * (1 << 28)
-    assert "cpu_baseline" not in j  # rank 0 at N=1 only
+    assert "cpu_baseline" not in j  # --cpu-seconds 0 (with a budget the leg runs at every N: test_both_bench_forms_folded_onto_one_gpu)
     # one row per rank through the control plane: who ran where, each rank's own kernel times and fractions
     rows = j["ranks"]
     assert [r["rank"] for r in rows] == [0, 1] and rows[0]["pid"] != rows[1]["pid"]
@@ -136,7 +170,9 @@ def test_two_rank_launch_path_shares_one_gpu():
         assert r["encode_ms"]["n"] == 2 and 0 < r["encode_frac"] < 1 and 0 < r["decode_frac"] < 1
         assert r["configs4_shard"]["nt"] == 1 << 29 and r["configs4_shard"]["round_trip_verified"] is True
     assert rows[1]["configs4_shard"]["first_nt"] == 1 << 29
-    assert j["devices"] == {"distinct": 1, "shared_gpu_test_hook": True, "data_path_collective": None, "control_plane": "gloo"}
+    d = j["devices"]
+    assert (d["distinct"], d["expected_distinct"], d["shared_gpu_test_hook"], d["data_path_collective"], d["control_plane"], d["processes"]) == (1, 2, True, None, "gloo", 2)
+    assert d["not_an_spx_mi355x"] == [] or all(x["chip"] for x in d["not_an_spx_mi355x"])  # an SPX MI355X here; anything else is named
     o = j["roofline_over_ranks"]
     assert o["encode_frac"]["min"] == min(r["encode_frac"] for r in rows) and o["encode_frac"]["max"] == max(r["encode_frac"] for r in rows)
     assert o["encode_read_view_frac"]["min"] <= o["encode_read_view_frac"]["max"]

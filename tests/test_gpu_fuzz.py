@@ -116,13 +116,14 @@ def test_five_letter_codec_fuzz(oracle, small_nt, seed):
 
 
 @pytest.fixture()
-def alias():
-    """cnt_test_alias_devices(1) for one test: shard k -> device k % count on the 1-GPU box"""
+def alias(hooks_build):
+    """the test-hooks build with cnt_test_alias_devices(1) for one test: shard k -> device k % count on the 1-GPU box (the
+    product library has no such switch)"""
     from cute_nucleotides_amd import sharding
 
-    prev = sharding.alias_devices(True)
+    sharding.alias_devices(True)
     yield
-    sharding.alias_devices(prev)
+    sharding.alias_devices(False)
 
 
 @pytest.mark.parametrize("seed", range(3 * SEEDS))

@@ -1,6 +1,8 @@
 """The sharded tier with ndev > 1 (BASELINE.json configs[4]: "chunk-sharded across 8 x MI355X ... no
 collective; per-GPU outputs concatenated on the host").  The GPU box has ONE device, so these tests
-switch on the library's test support cnt_test_alias_devices(1) (shard k -> device k % count): the
+load the TEST-HOOKS build of the library (tests/libcute_nt_hip_hooks.so: the product's sources and kernels
+with -DCNT_TEST_HOOKS -- the product itself exports no hook) and switch on cnt_test_alias_devices(1)
+(shard k -> device k % count); whatever needs no hook (ndev = 1, argument checks) runs on the product: the
 partition arithmetic of cnt_*_sharded, the multi-worker pool, the empty-shard path, the ragged
 last shard and the per-shard output offsets all run exactly as they would on an 8-GPU node -- only the
 device binding is folded onto cuda:0.  Everything is compared with the CPU oracle bit for bit, with
@@ -16,19 +18,36 @@ pytestmark = pytest.mark.gpu
 GUARD = 8  # words / 64 bytes of sentinel on both sides of every output
 
 
+class _ActiveLibrary:
+    """forwards to whichever build is active at the time of the call: the product, or -- inside a test that took `alias` /
+    `hooks_build` -- the test-hooks build"""
+
+    def __getattr__(self, name):
+        from cute_nucleotides_amd import _lib
+
+        return getattr(_lib.lib(), name)
+
+
 @pytest.fixture(scope="module")
 def L():
-    from cute_nucleotides_amd import _lib
-
-    return _lib.lib()
+    return _ActiveLibrary()
 
 
 @pytest.fixture()
-def alias(L):
-    """cnt_test_alias_devices(1) for the duration of one test (an explicit call: no environment variable exists)"""
-    prev = L.cnt_test_alias_devices(1)
+def alias(hooks_build):
+    """the test-hooks build with cnt_test_alias_devices(1) for the duration of one test (an explicit call: no environment
+    variable exists, and the product library has no such switch at all)"""
+    assert hooks_build.cnt_test_alias_devices(1) == 0
     yield
-    L.cnt_test_alias_devices(prev)
+    hooks_build.cnt_test_alias_devices(0)
+
+
+def _production_path():
+    """ndev == 1 needs no hook: that case runs on the PRODUCT library (the fixture's teardown restores the build)"""
+    from cute_nucleotides_amd import _lib
+
+    _lib.use_build("product")
+    assert not hasattr(_lib.lib(), "cnt_test_alias_devices")
 
 
 def _p(a, off_bytes=0):
@@ -108,13 +127,34 @@ def test_sharded_off_alphabet_bytes_and_lowercase(L, oracle, alias):
 def test_alias_hook_is_opt_in_and_bounded(L, oracle, monkeypatch):
     import torch
 
-    from cute_nucleotides_amd import _lib
+    from cute_nucleotides_amd import _lib, sharding
 
     count = torch.cuda.device_count()
     n = oracle.fill_random_acgt(40000, 3)
     out = np.zeros(1250, dtype=np.uint64)
-    assert L.cnt_test_alias_devices(0) == 0  # off by default
     monkeypatch.setenv("CNT_SHARD_ALIAS_DEVICES", "1")  # round 2's environment hook is gone: a variable changes nothing
+    # the PRODUCT: no hook exported, no switch inside, more shards than devices is always CNT_ENODEV
+    assert _lib.active_build() == "product" and not hasattr(_lib.lib(), "cnt_test_alias_devices")
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, count + 1) == _lib.CNT_ENODEV
+    assert sharding.alias_devices(False) is False
+    with pytest.raises(RuntimeError, match="hooks"):
+        sharding.alias_devices(True)
+    # the test-hooks build: off by default, bounded
+    prev = _lib.use_build("hooks")
+    try:
+        _alias_hook_checks(L, _lib, n, out, count)
+    finally:
+        L.cnt_test_alias_devices(0)
+        _lib.use_build(prev)
+    assert np.array_equal(out, oracle.n_to_bits_lut(n))
+    # argument errors come before any device work, as for the unsharded calls
+    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), 1249, 4) == _lib.CNT_ECAP
+    assert L.cnt_bits_to_n_sharded(_p(out), 1250, 40001, _p(n), 4) == _lib.CNT_ELEN
+    assert L.cnt_bits_to_n2_sharded(_p(out), 1250, 1250 * 27 + 1, _p(n), 4) == _lib.CNT_ELEN
+
+
+def _alias_hook_checks(L, _lib, n, out, count):
+    assert L.cnt_test_alias_devices(0) == 0  # off by default
     assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, count + 1) == _lib.CNT_ENODEV  # production behaviour
     assert L.cnt_test_alias_devices(1) == 0
     try:
@@ -122,11 +162,6 @@ def test_alias_hook_is_opt_in_and_bounded(L, oracle, monkeypatch):
         assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), out.size, 64) == 0
     finally:
         assert L.cnt_test_alias_devices(0) == 1
-    assert np.array_equal(out, oracle.n_to_bits_lut(n))
-    # argument errors come before any device work, as for the unsharded calls
-    assert L.cnt_n_to_bits_sharded(_p(n), n.size, _p(out), 1249, 4) == _lib.CNT_ECAP
-    assert L.cnt_bits_to_n_sharded(_p(out), 1250, 40001, _p(n), 4) == _lib.CNT_ELEN
-    assert L.cnt_bits_to_n2_sharded(_p(out), 1250, 1250 * 27 + 1, _p(n), 4) == _lib.CNT_ELEN
 
 
 def test_worker_placement_and_copy_thread_budget(L, oracle, alias, monkeypatch):
@@ -197,7 +232,7 @@ def test_device_resident_shards_match_the_oracle(L, oracle, alias, monkeypatch, 
     from cute_nucleotides_amd import sharding
 
     if ndev == 1:
-        L.cnt_test_alias_devices(0)  # the production path: one real device, no hook
+        _production_path()  # one real device, no hook: the product library
     sizes = [(1 << 21) + 13, 0, 40000, 2048 * 5, 77, (1 << 20), 16384 * 3 + 1, 1][:ndev]
     for five in (False, True):
         gen = oracle.fill_random_acgtn if five else oracle.fill_random_acgt
@@ -240,7 +275,7 @@ def test_enqueue_only_queue_runs_steps_ahead_and_matches_the_oracle(L, oracle, a
     from cute_nucleotides_amd import sharding
 
     if ndev == 1:
-        L.cnt_test_alias_devices(0)
+        _production_path()
     sizes = [(1 << 20) + 13, 0, 40000, 2048 * 5, 77, (1 << 19), 16384 * 3 + 1, 1][:ndev]
     steps = 3
     for five in (False, True):
@@ -353,6 +388,168 @@ def test_enqueue_only_queue_error_paths(L, alias):
     assert torch.cuda.current_device() == 0
 
 
+@pytest.mark.parametrize("ndev", [1, 2, 8])
+@pytest.mark.parametrize("form", ["events", "adopted_streams"])
+def test_queue_runs_behind_the_callers_streams_without_any_host_sync(L, oracle, alias, ndev, form):
+    """generator -> encode -> decode -> consumer on N devices with the host never waiting.
+    Every shard is FILLED on a torch stream of its own that first sleeps on the device for milliseconds (so the codec ops
+    are enqueued long before their input exists); the queue is ordered behind that stream on the device -- form "events":
+    cnt_sharded_dev_wait_event on the producer's event, cnt_sharded_dev_record_event for the consumer stream; form
+    "adopted_streams": cnt_sharded_dev_open_on_streams, everything on the caller's stream -- and a consumer copies the
+    outputs away behind the queue.  The ONLY host synchronisation is at the very end.  Outputs against the oracle; the
+    control without the ordering encodes the not-yet-written buffer (the test has teeth)."""
+    import torch
+
+    from cute_nucleotides_amd import devutil, sharding
+
+    if ndev == 1:
+        _production_path()
+    sizes = [(1 << 22) + 13, 40000, 2048 * 7, 0, (1 << 20), 77, 16384 * 3 + 1, 1][:ndev]
+    seeds = [7100 + k for k in range(ndev)]
+    dev = torch.device("cuda", 0)
+    d_in = [torch.zeros(s, dtype=torch.uint8, device=dev) for s in sizes]
+    d_pk = [torch.zeros((s + 31) // 32, dtype=torch.int64, device=dev) for s in sizes]
+    d_out = [torch.zeros(s, dtype=torch.uint8, device=dev) for s in sizes]
+    sink_n = [torch.zeros(s, dtype=torch.uint8, device=dev) for s in sizes]
+    sink_w = [torch.zeros((s + 31) // 32, dtype=torch.int64, device=dev) for s in sizes]
+    producers = [torch.cuda.Stream(device=dev) for _ in sizes]
+    consumers = producers if form == "adopted_streams" else [torch.cuda.Stream(device=dev) for _ in sizes]
+    filled = [torch.cuda.Event() for _ in sizes]
+    done = [torch.cuda.Event() for _ in sizes]
+    for e, st in zip(done, consumers):
+        e.record(st)  # torch creates the HIP event on first record: the queue re-records it below
+    torch.cuda.synchronize()  # allocation and zeroing are over: from here on the host never waits until the final check
+
+    def produce(k):
+        with torch.cuda.stream(producers[k]):
+            torch.cuda._sleep(40_000_000)  # the producer is late: milliseconds of device time before the fill even starts
+            if sizes[k]:
+                devutil.fill_random_acgt(d_in[k], seeds[k])
+            filled[k].record(producers[k])
+
+    def consume(k):
+        with torch.cuda.stream(consumers[k]):
+            sink_n[k].copy_(d_out[k], non_blocking=True)
+            sink_w[k].copy_(d_pk[k], non_blocking=True)
+
+    q = sharding.DevQueue(streams=producers) if form == "adopted_streams" else sharding.DevQueue(ndev, timed=True)
+    assert q.ndev == ndev
+    for k in range(ndev):
+        produce(k)
+        if form == "events":
+            q.wait_event(k, filled[k])
+    q.n_to_bits(d_in, d_pk)
+    q.bits_to_n(d_pk, sizes, d_out)
+    for k in range(ndev):
+        if form == "events":
+            q.record_event(k, done[k])
+            consumers[k].wait_event(done[k])
+        consume(k)
+    still_running = not filled[0].query()  # everything is enqueued and shard 0's producer has not even finished: nobody waited
+    for st in consumers:
+        st.synchronize()  # the one host synchronisation, at the end of the pipeline
+    assert still_running, "the host was stopped somewhere between the producer and the consumer"
+    for k, s in enumerate(sizes):
+        host = oracle.fill_random_acgt(s, seeds[k]) if s else np.empty(0, dtype=np.uint8)
+        want = oracle.n_to_bits_lut(host) if s else np.empty(0, dtype=np.uint64)
+        assert np.array_equal(sink_w[k].cpu().numpy().view(np.uint64), want), (form, ndev, k)
+        assert np.array_equal(sink_n[k].cpu().numpy(), host), (form, ndev, k)
+    if form == "events":
+        ms = q.wait()
+        assert len(ms) == ndev and all(m > 0 for m, s in zip(ms, sizes) if s)  # the batch's start event sits BEHIND the wait
+        assert max(ms) < 50.0, ms  # ... so the producer's sleep is not in the ops' device times
+    q.close()
+    if form == "adopted_streams":  # close() left the caller's streams alone: they still work
+        with torch.cuda.stream(producers[0]):
+            d_out[0].fill_(65)
+        producers[0].synchronize()
+        assert int(d_out[0][0].item()) == 65
+    elif ndev == 1:
+        # control: the same pipeline WITHOUT cnt_sharded_dev_wait_event encodes the buffer before the producer wrote it
+        d_in[0].zero_()
+        torch.cuda.synchronize()
+        with sharding.DevQueue(1) as q2:
+            produce(0)
+            q2.n_to_bits(d_in, d_pk)
+            raced = not filled[0].query()
+            q2.wait()
+        torch.cuda.synchronize()
+        if raced:
+            assert not np.array_equal(d_pk[0].cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(oracle.fill_random_acgt(sizes[0], seeds[0])))
+    assert torch.cuda.current_device() == 0
+
+
+def test_queue_ordering_entry_points_error_paths_and_the_timed_op_cap(L, alias):
+    import torch
+
+    from cute_nucleotides_amd import _lib, sharding
+
+    q = ctypes.c_void_p()
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    two = (ctypes.c_void_p * 2)(st[0].cuda_stream, st[1].cuda_stream)
+    assert L.cnt_sharded_dev_open_on_streams(2, None, 0, ctypes.byref(q)) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_open_on_streams(2, (ctypes.c_void_p * 2)(st[0].cuda_stream, None), 0, ctypes.byref(q)) == _lib.CNT_EINVAL  # never the legacy default stream
+    assert L.cnt_sharded_dev_open_on_streams(65, two, 0, ctypes.byref(q)) == _lib.CNT_ENODEV
+    assert L.cnt_sharded_dev_open_on_streams(2, two, 0, ctypes.byref(q)) == 0 and q.value
+    ev = torch.cuda.Event()
+    ev.record()
+    h = ctypes.c_void_p(ev.cuda_event)
+    assert L.cnt_sharded_dev_wait_event(q, 2, h) == _lib.CNT_EINVAL and L.cnt_sharded_dev_wait_event(q, -1, h) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_wait_event(q, 0, None) == _lib.CNT_EINVAL and L.cnt_sharded_dev_record_event(q, 1, None) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_wait_event(q, 1, h) == 0 and L.cnt_sharded_dev_record_event(q, 1, h) == 0
+    assert L.cnt_sharded_dev_wait(q, None) == 0 and L.cnt_sharded_dev_close(q) == 0
+    assert L.cnt_sharded_dev_wait_event(q, 0, h) == _lib.CNT_EINVAL  # closed handle
+    with pytest.raises(ValueError):
+        sharding.DevQueue(streams=[0])
+    with pytest.raises(ValueError):
+        sharding.DevQueue(3, streams=st)
+    # a timed queue holds CNT_QUEUE_MAX_TIMED_OPS ops per batch: the next enqueue is CNT_ECAP and queues nothing; after a wait
+    # the events are recycled (ADVICE r04: the event pool used to grow without bound)
+    a = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(2, dtype=torch.int64, device="cuda")
+    with sharding.DevQueue(1, timed=True) as dq:
+        for _ in range(_lib.CNT_QUEUE_MAX_TIMED_OPS):
+            dq.n_to_bits([a], [o])
+        with pytest.raises(_lib.CuteNtError) as e:
+            dq.n_to_bits([a], [o])
+        assert e.value.status == _lib.CNT_ECAP
+        assert len(dq.wait()) == 1 and dq.op_ms(_lib.CNT_QUEUE_MAX_TIMED_OPS - 1)[0] >= 0.0
+        dq.n_to_bits([a], [o])
+        dq.wait()
+    with sharding.DevQueue(1) as dq:  # untimed: no per-op state, no limit
+        for _ in range(_lib.CNT_QUEUE_MAX_TIMED_OPS + 8):
+            dq.n_to_bits([a], [o])
+        dq.wait()
+
+
+def test_fused_round_trip_through_the_queue(L, oracle, alias):
+    """cnt_round_trip_sharded_dev_enqueue: BASELINE.json configs[3]'s fused pass on every shard (ragged, empty, misaligned)"""
+    import torch
+
+    from cute_nucleotides_amd import sharding
+
+    sizes = [(1 << 21) + 5, 0, 40000, 4096 * 9]
+    host = [oracle.fill_random_acgt(s, 8800 + k) if s else np.empty(0, dtype=np.uint8) for k, s in enumerate(sizes)]
+    bufs = [torch.zeros(s + 64, dtype=torch.uint8, device="cuda") for s in sizes]
+    d_in = []
+    for k, (b, h) in enumerate(zip(bufs, host)):
+        v = b[k : k + h.size]
+        if h.size:
+            v.copy_(torch.from_numpy(h))
+        d_in.append(v)
+    d_pk = [torch.zeros((s + 31) // 32, dtype=torch.int64, device="cuda") for s in sizes]
+    d_back = [torch.zeros(s, dtype=torch.uint8, device="cuda") for s in sizes]
+    torch.cuda.synchronize()
+    with sharding.DevQueue(len(sizes), timed=True) as q:
+        q.round_trip(d_in, d_pk, d_back)
+        ms = q.wait()
+    for k, h in enumerate(host):
+        want = oracle.n_to_bits_lut(h) if h.size else np.empty(0, dtype=np.uint64)
+        assert np.array_equal(d_pk[k].cpu().numpy().view(np.uint64), want), k
+        assert np.array_equal(d_back[k].cpu().numpy(), h), k
+        assert ms[k] > 0 or h.size == 0
+
+
 def test_device_resident_shards_error_paths(L, oracle, alias):
     import torch
 
@@ -433,8 +630,8 @@ def test_sharded_dev_wrappers_validate_their_lists(L):
     with pytest.raises(ValueError):
         sharding.bits_to_n_sharded_dev([w, w], [4096, 4096], outs=[d])
     if torch.cuda.device_count() == 1:
-        # two shards, one device, no test support switched on: the placement check passes (k % 1 == 0) and the library refuses
-        assert L.cnt_test_alias_devices(0) == 0
+        # two shards, one device, the product library: the placement check passes (k % 1 == 0) and the library refuses
+        assert _lib.active_build() == "product"
         with pytest.raises(_lib.CuteNtError) as e:
             sharding.n_to_bits_sharded_dev([d, d])
         assert e.value.status == _lib.CNT_ENODEV

@@ -45,8 +45,22 @@ def _thp_mode():
 
 @pytest.fixture(scope="module")
 def L():
+    """the TEST-HOOKS build (tests/libcute_nt_hip_hooks.so, -DCNT_TEST_HOOKS): the product library exports no cnt_test_* symbol"""
+    from cute_nucleotides_amd import _lib, build
+
+    build.build_hooks()
+    prev = _lib.use_build("hooks")
+    lib = _lib.lib()
+    _lib.use_build(prev)
+    return lib
+
+
+@pytest.fixture(scope="module")
+def P():
+    """the PRODUCT library, for the real host-tier calls"""
     from cute_nucleotides_amd import _lib
 
+    assert _lib.active_build() == "product"
     return _lib.lib()
 
 
@@ -91,7 +105,8 @@ def test_fresh_output_is_advised_and_a_half_warm_one_only_where_it_is_fresh(L):
 
 @needs_smaps
 @pytest.mark.gpu
-def test_real_calls_leave_a_warm_output_alone_and_advise_a_fresh_one(L, oracle):
+def test_real_calls_leave_a_warm_output_alone_and_advise_a_fresh_one(P, oracle):
+    L = P
     n_len = 1 << 26
     n = oracle.fill_random_acgt(n_len, 5)
     bits = oracle.n_to_bits_lut(n)

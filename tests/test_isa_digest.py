@@ -65,6 +65,21 @@ def test_product_code_object_holds_no_lab_kernels(isa):
     assert len(names) < 60, len(names)
 
 
+def test_test_hooks_build_has_the_products_device_code():
+    """tests/libcute_nt_hip_hooks.so (-DCNT_TEST_HOOKS: cnt_test_alias_devices / _advise_output /
+    _round_trip_plan) is what the N > 1 sharded tests load instead of the product -- its DEVICE code is the product's, byte for
+    byte: the macro touches host code only, so what those tests exercise on the GPU is what ships."""
+    import isa_digest
+
+    import re
+
+    # what may differ: source paths, the compiler banner, and __hip_cuid_<hash> (a one-byte symbol named after a hash of the
+    # compiler's command line, which contains the -D); every instruction, kernel descriptor and metadata line may not
+    strip = lambda asm: re.sub(r"__hip_cuid_[0-9a-f]+", "__hip_cuid", "\n".join(l for l in asm.splitlines() if not l.lstrip().startswith((".file", ".ident", "; "))))
+    product, hooks = strip(isa_digest.assembly()), strip(isa_digest.assembly(hooks=True))
+    assert product.count("s_endpgm") > 30 and hooks == product
+
+
 def test_every_shipped_kernel_is_lean(isa):
     isa_digest, found = isa
     for label, name in isa_digest.SHIPPED:

@@ -18,9 +18,14 @@ TILE = 4096
 
 @pytest.fixture(scope="module")
 def L():
-    from cute_nucleotides_amd import _lib
+    """the TEST-HOOKS build (tests/libcute_nt_hip_hooks.so, -DCNT_TEST_HOOKS): the product library exports no cnt_test_* symbol"""
+    from cute_nucleotides_amd import _lib, build
 
-    return _lib.lib()
+    build.build_hooks()
+    prev = _lib.use_build("hooks")
+    lib = _lib.lib()
+    _lib.use_build(prev)
+    return lib
 
 
 def _plan(L, a_n, a_bits, a_back, n_len, flags):

@@ -57,6 +57,14 @@ def test_binding_keeps_the_reference_signatures_and_is_well_formed():
                 r"pub struct ShardedDevQueue \{", r"impl Drop for ShardedDevQueue \{", r"pub fn enqueue_n_to_bits\(&mut self,", r"pub fn enqueue_bits_to_n\(&mut self,",
                 r"pub fn wait\(&mut self\) -> Vec<f32> \{"):
         assert re.search(sig, hip), sig
+    # the queue's shard count is what the LIBRARY resolved (cnt_sharded_dev_shards), never the caller's
+    # `ndev` (0 = all devices would have sized wait()'s and op_ms()'s buffers with zero floats for the C side to overrun)
+    q = hip.split("impl ShardedDevQueue {", 1)[1].split("impl Drop for ShardedDevQueue", 1)[0]
+    assert "cnt_sharded_dev_shards(handle, &mut n)" in q and "ndev: n as usize" in q and "ShardedDevQueue { handle, ndev }" not in q
+    assert q.count("ShardedDevQueue::adopt(handle)") == 2 and "vec![0f32; self.ndev]" in q
+    for sig in (r"pub fn on_streams\(streams: &\[\*mut c_void\], timed: bool\) -> ShardedDevQueue \{", r"pub fn wait_event\(&mut self, k: usize, event: \*mut c_void\) \{",
+                r"pub fn record_event\(&mut self, k: usize, event: \*mut c_void\) \{"):
+        assert re.search(sig, hip), sig
     # the reference's panic text wherever a decoder checks `len` (n_to_bits.rs:52-54)
     assert hip.count('panic!("The length is greater than the number of nucleotides!")') >= 6
     # every call of a status-returning C symbol goes through check(...) (the three Drop impls and the bool probe excepted)
