@@ -1,7 +1,21 @@
 #!/usr/bin/env python3
 """cnt_bits_to_n_dev with the packed stream entered at every kind of offset inside a 4-KiB page (the output peeled to a page as
-always): the shipped four-tiles-per-XCD map against plain dispatch order (lab variant 42), same buffers, one JSON line per offset.
-Answers "why does decode off the grid cost between 0 and 12 %": the XCD map wants the packed stream's 4-KiB pieces on pages."""
+always).  Round 4 asked "why does decode off the grid cost between 0 and 12 %" and answered "the four-tiles-per-XCD map wants
+the packed stream's 4-KiB pieces on pages".  Round 5 asks whether MOVING THE TURNS fixes it: peeling
+k = 0..3 more output pages into the head moves every turn's packed piece by k KiB (device_tier.inc decode_turn_pages), so
+for every offset this script times, INTERLEAVED over several rounds in one process on the same buffers,
+
+    k0..k3   the shipped map with k further pages peeled (k0 = what round 4 shipped),
+    after    rule 10: the k that starts the turns in [page, page + 1 KiB) of the packed buffer,
+    nearest  rule 11: the k that starts them within 512 B of a page boundary, either side,
+    shipped  the product rule (tuning value -1),
+    plain    plain dispatch order (lab variant 42; no turns to misplace),
+
+and prints one JSON line per offset pair with the GB/s (1.25 B/nt) of each: median over rounds of the mean of `it` queued
+launches, plus the per-k packed residue r_k = (first tile's packed byte address) mod 4096.
+
+    python bench/decode_off_grid.py [--log2-nt 34] [--rounds 6] [--it 4] [--quick]"""
+import argparse
 import json
 import os
 import statistics
@@ -14,40 +28,72 @@ import torch  # noqa: E402
 import cute_nucleotides_amd as cn  # noqa: E402
 from cute_nucleotides_amd import _lib, devutil  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--log2-nt", type=int, default=34)
+ap.add_argument("--rounds", type=int, default=6)
+ap.add_argument("--it", type=int, default=4)
+ap.add_argument("--quick", action="store_true", help="eight offsets instead of the full sweep")
+a = ap.parse_args()
+
 _lib.use_lab_build()
-n = 1 << 34
-pad = 16384
+n = 1 << a.log2_nt
+pad = 32768
 b_in = torch.empty(n + pad, dtype=torch.uint8, device="cuda")
 b_out = torch.empty(n + pad, dtype=torch.uint8, device="cuda")
 b_pk = torch.empty(n // 32 + pad // 8, dtype=torch.int64, device="cuda")
 devutil.fill_random_acgt(b_in[:n], 1)
+base_out, base_pk = b_out.data_ptr(), b_pk.data_ptr()
+assert base_out % 4096 == 0 and base_pk % 4096 == 0
 
 
-def timed(fn, it=4):
-    fn()
-    torch.cuda.synchronize()
-    ms = []
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(it):
-            fn()
-        e1.record()
-        e1.synchronize()
-        ms.append(e0.elapsed_time(e1) / it)
-    return statistics.median(ms)
+def once(fn, it):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / it
 
 
-cases = [(0, 0), (0, 8), (0, 1032), (0, 2056)] + [(16, p) for p in (0, 8, 264, 520, 776, 1032, 1288, 1544, 1800, 2056, 2312, 2568, 2824, 3080, 3088, 3336, 3592, 3848, 4088)]
+# (ascii offset, packed offset): the ASCII offsets 0 / 16 keep the stream kernel (head a multiple of 16 nt), 5 / 77 take the
+# shifted kernel (two dwords through v_alignbit); packed offsets walk the page in 256-B steps plus the neighbours of 0 and 1 KiB
+packed = [0, 8, 16, 64, 128, 256, 264, 512, 520, 776, 1016, 1024, 1032, 1288, 1544, 1800, 2048, 2056, 2312, 2568, 2824, 3072, 3080, 3088, 3336, 3592, 3848, 4088]
+cases = [(0, p) for p in packed] + [(16, p) for p in packed] + [(5, p) for p in (0, 8, 264, 1032, 2056, 3080)] + [(77, p) for p in (8, 1544, 3592)]
+if a.quick:
+    cases = [(0, 0), (0, 8), (0, 1032), (0, 2056), (16, 8), (16, 264), (16, 2312), (5, 264)]
+
+MODES = (("k0", 0, 0), ("k1", 0, 1), ("k2", 0, 2), ("k3", 0, 3), ("after", 0, 10), ("nearest", 0, 11), ("shipped", 0, -1), ("plain", 42, -1))
 for a_off, p_off in cases:
     d_out = b_out[a_off : a_off + n]
     d_pk = b_pk[p_off // 8 : p_off // 8 + n // 32]
     cn.n_to_bits_dev(b_in[:n], out=d_pk)
-    head = (4096 - a_off) % 4096
-    row = {"ascii_off": a_off, "packed_off": p_off, "first_tile_packed_byte_mod_4096": (p_off + 4 * (head >> 4)) % 4096}
-    for v, name in ((0, "xcd_quads_GBs"), (42, "plain_order_GBs")):
-        devutil.set_tuning("decode", v)
-        row[name] = round(1.25 * n / timed(lambda: cn.bits_to_n_dev(d_pk, n, out=d_out)) / 1e6, 1)
+    head = (4096 - (base_out + a_off) % 4096) % 4096
+    r0 = (base_pk + p_off + 4 * (head >> 4)) % 4096
+    row = {"ascii_off": a_off, "packed_off": p_off, "kernel": "stream" if head % 16 == 0 else "shifted", "r": r0,
+           "r_k": [(r0 + 1024 * k) % 4096 for k in range(4)], "k_after": (4 - (r0 >> 10)) & 3, "k_nearest": (4 - ((r0 + 512) >> 10)) & 3}
+    ms = {name: [] for name, _, _ in MODES}
+
+    def call():
+        cn.bits_to_n_dev(d_pk, n, out=d_out)
+
+    for name, variant, rot in MODES:  # warm every mode once (and check it)
+        devutil.set_tuning("decode", variant)
+        devutil.set_tuning("decode_rot", rot)
+        call()
+    torch.cuda.synchronize()
+    for rnd in range(a.rounds):
+        order = MODES if rnd % 2 == 0 else MODES[::-1]  # alternate the order: a drift does not favour one mode
+        for name, variant, rot in order:
+            devutil.set_tuning("decode", variant)
+            devutil.set_tuning("decode_rot", rot)
+            ms[name].append(once(call, a.it))
+    for name, _, _ in MODES:
+        row[name] = round(1.25 * n / statistics.median(ms[name]) / 1e6, 1)
+        row[name + "_best"] = round(1.25 * n / min(ms[name]) / 1e6, 1)
     devutil.set_tuning("decode", 0)
-    assert devutil.count_mismatch(b_in[:n].contiguous(), d_out.contiguous()) == 0
+    devutil.set_tuning("decode_rot", 3)  # the largest head: 3 pages + the peel, all through the edge items
+    call()
+    assert devutil.count_mismatch(b_in[:n].contiguous(), d_out.contiguous()) == 0, (a_off, p_off)
+    devutil.set_tuning("decode_rot", -1)
     print(json.dumps(row), flush=True)

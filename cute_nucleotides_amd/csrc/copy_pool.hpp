@@ -39,7 +39,10 @@ class CopyPool {
     // condition variable -- inside a pipelined call it never sleeps, so a copy starts within a microsecond instead of the
     // 20-50 us of a condition-variable wake-up (which made 8 threads SLOWER than 4 in the first version of this pool).
     void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false) {
-        if (bytes < kMinPar) {  // small copies never start (or wake) the team
+        // small copies never start (or wake) the team: below kMinPar always the caller's memcpy; up to kSmallCopy (the band
+        // the zero-copy small calls fall into) only a team that is ALREADY running is joined -- an isolated mid-size call
+        // must not pay for creating up to seven threads that then spin for 150 us each
+        if (bytes < kMinPar || (bytes <= kSmallCopy && !started_)) {
             memcpy(dst, src, bytes);
             return;
         }

@@ -99,6 +99,8 @@ std::atomic<int> g_round_trip_window_map{0};  // tile map of the any-alignment f
 inline int tune_round_trip_window_map() { return g_round_trip_window_map.load(std::memory_order_relaxed); }
 std::atomic<int> g_round_trip_plan{kRoundTripDefaultPlan};  // pricing of the any-alignment fused launch plan (device_tier.inc round_trip_plan): 3 = shipped; 0 tiles on d_back's pages, 1 windows on d_n's pages, 2 shortest read-ahead
 inline int tune_round_trip_plan() { return g_round_trip_plan.load(std::memory_order_relaxed); }
+std::atomic<int> g_decode_rot{-1};  // further 4-KiB output pages peeled in front of decode's tiles (device_tier.inc decode_turn_pages): -1 the shipped rule, 0..3 forced, 10 / 11 the two candidate rules
+inline int tune_decode_rot() { return g_decode_rot.load(std::memory_order_relaxed); }
 #else
 constexpr int tune_encode() { return 0; }
 constexpr int tune_decode() { return 0; }
@@ -109,6 +111,7 @@ constexpr int tune_round_trip_shape() { return 0; }
 constexpr uint32_t tune_round_trip_cap() { return kRoundTripDefaultCap; }
 constexpr int tune_round_trip_window_map() { return 0; }
 constexpr int tune_round_trip_plan() { return kRoundTripDefaultPlan; }
+constexpr int tune_decode_rot() { return -1; }
 #endif
 
 inline unsigned generic_grid(uint64_t items) {
@@ -455,6 +458,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_plan")) {
         if (value < 0 || value > 3) return CNT_EINVAL;
         g_round_trip_plan.store(value);
+    } else if (!strcmp(key, "decode_rot")) {
+        if (value < -1 || (value > 3 && value != 10 && value != 11)) return CNT_EINVAL;
+        g_decode_rot.store(value);
     } else if (!strcmp(key, "reduce_persistent")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_reduce_persistent.store(value);
@@ -505,6 +511,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "decode2_variants")) *value = kNumDecode2Variants;
 #ifdef CNT_LAB_VARIANTS
     else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
+    else if (!strcmp(key, "decode_rot")) *value = g_decode_rot.load();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "hamming_order")) *value = g_hamming_order.load();
     else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();

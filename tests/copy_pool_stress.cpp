@@ -88,6 +88,17 @@ int main(int argc, char** argv) {
         printf("ok stall\n");
         return 0;
     }
+    {  // a copy of 512 KiB .. 1 MiB never STARTS the team (it only joins one that is running already)
+        std::vector<uint8_t> src((size_t)4 << 20, 0x33), dst((size_t)4 << 20, 0);
+        CopyPool pool;
+        pool.copy(dst.data(), src.data(), (size_t)768 << 10, false);
+        pool.copy(dst.data(), src.data(), (size_t)1 << 20, true);
+        if (pool.spawned() != 0 || memcmp(dst.data(), src.data(), (size_t)1 << 20) != 0) { printf("FAILED: a mid-size copy started %d helper threads\n", pool.spawned()); return 1; }
+        pool.copy(dst.data(), src.data(), (size_t)3 << 20, false);  // a large copy does
+        const int team = pool.spawned();
+        pool.copy(dst.data() + 5, src.data(), (size_t)768 << 10, false);  // ... and a mid-size one joins it
+        if (team < 1 || pool.spawned() != team || memcmp(dst.data() + 5, src.data(), (size_t)768 << 10) != 0) { printf("FAILED: team %d -> %d\n", team, pool.spawned()); return 1; }
+    }
     const int copies = argc > 1 ? atoi(argv[1]) : 600, threads = argc > 2 ? atoi(argv[2]) : 3;
     const size_t max_bytes = (size_t)(argc > 3 ? atoi(argv[3]) : 6) << 20;
     std::vector<int> bad(threads, 0);

@@ -104,7 +104,7 @@ def test_both_bench_forms_folded_onto_one_gpu(n):
     assert all(r["chip"] == j["ranks"][0]["chip"] and r["chip"]["compute_units"] > 0 and r["chip"]["xcds"] >= 1 and r["hbm_before"]["free_GiB"] > 1 for r in j["ranks"])
     f = j["fused_round_trip"]  # the fused pass of every shard through the same queue, verified against the two-pass outputs
     assert f["ms_stats"]["verified"] is True and 0 < f["frac_over_ranks"]["min"] <= f["frac_over_ranks"]["max"] < 1.2 and f["bytes_per_nt"] == 2.25
-    assert 1000.0 < j["ceilings"]["rank0"]["read_only"]["GBs"] < 8000.0 and j["ceilings"]["encode_vs"]["of_read4_write1_ceiling"] > 0.3
+    assert 1000.0 < j["ceilings"]["rank0"]["read_only"]["GBs"] < 8000.0 and j["ceilings"]["encode_vs"]["of_read4_write1_ceiling"] > 0.5 / n  # N folded shards share this box's bandwidth
     so = j["scaling_overhead"]
     assert so["shards_per_device"] == n and so["per_step_us"] == j["scaling_overhead_us"]
     assert so["per_step_us"] <= 31.0, so  # 1 % of a 3.1-ms kernel; folded shards overlap, so the number is usually negative
