@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libcute_nt_hip.so")
 # never loaded unless a bench script or a test asks for it with use_lab_build(): the product library has no run-time kernel
 # selection (cnt_set_tuning answers CNT_EINVAL there).
 LAB_LIB_PATH = os.path.join(os.path.dirname(HERE), "bench", "libcute_nt_hip_lab.so")
-# The TEST-HOOKS build (-DCNT_TEST_HOOKS: the product's kernels + the three cnt_test_* hooks), under tests/: what the N > 1
+# The TEST-HOOKS build (-DCNT_TEST_HOOKS: the product's kernels + the cnt_test_* hooks), under tests/: what the N > 1
 # sharded tests load to fold shards onto a 1-GPU box.  The product library exports no hook and holds no switch.
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcute_nt_hip_hooks.so")
 
@@ -99,6 +99,7 @@ TEST_HOOK_SIGNATURES = {
     "cnt_test_alias_devices": (_int, [_int]),
     "cnt_test_advise_output": (_int, [_vp, _sz]),
     "cnt_test_round_trip_plan": (_int, [_u64, _u64, _u64, _u64, _uint, ctypes.POINTER(_u64)]),
+    "cnt_test_decode_plan": (_int, [_u64, _u64, _u64, ctypes.POINTER(_u64)]),
 }
 CNT_QUEUE_MAX_TIMED_OPS = 4096
 

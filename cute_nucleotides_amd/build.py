@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libcute_nt_hip.so")
 # the same translation unit with -DCNT_LAB_VARIANTS: every measured kernel variant + the process-global tuning knobs that
 # select them (cnt_set_tuning).  Bench / test infrastructure, kept out of the product package on purpose.
 LAB_LIB = os.path.join(os.path.dirname(HERE), "bench", "libcute_nt_hip_lab.so")
-# ... and with -DCNT_TEST_HOOKS: the product's code plus the three cnt_test_* hooks (fold shards onto fewer devices, run
+# ... and with -DCNT_TEST_HOOKS: the product's code plus the cnt_test_* hooks (fold shards onto fewer devices, run
 # the huge-page advice alone, print the fused launch plan).  Test infrastructure: lives under tests/, loaded only by tests
 # (and by the bench forms when a test folds them onto one GPU); the product exports none of it.
 HOOKS_LIB = os.path.join(os.path.dirname(HERE), "tests", "libcute_nt_hip_hooks.so")

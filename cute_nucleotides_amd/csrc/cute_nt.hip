@@ -592,6 +592,15 @@ int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uin
     out[7] = kRoundTripAnySlackVecs;
     return CNT_OK;
 }
+int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t* out) {
+    if (!out || (a_bits & 7)) return CNT_EINVAL;
+    const uint64_t head = decode_head((uintptr_t)a_bits, (uintptr_t)a_out, len, tune_decode_rot());
+    out[0] = head;                                   // nucleotides in front of the first tile (edge items)
+    out[1] = (a_out + head) & 4095;                  // the first tile's output byte inside its page (0 for len >= 2^20)
+    out[2] = (a_bits + 4 * (head >> 4)) & 4095;      // the first tile's packed byte inside its page: where every XCD turn starts
+    out[3] = 2 * (head & 15);                        // bit phase of the packed stream (0: bits_to_n_stream, else bits_to_n_shifted)
+    return CNT_OK;
+}
 int cnt_test_advise_output(void* out, size_t bytes) {
     if (!out) return CNT_EINVAL;
     advise_huge_output(out, bytes);

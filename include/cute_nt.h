@@ -349,7 +349,7 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                4); as above the threads that exist are up to twice that minus one per shard */
 
 /* ---- test support: NOT part of libcute_nt_hip.so ----------------------------------------
- * The product library neither exports these three nor contains the state they touch (tests/test_abi.py checks its dynamic
+ * The product library neither exports these four nor contains the state they touch (tests/test_abi.py checks its dynamic
  * symbol table): like the reference's functions over immutable tables (n_to_bits.rs:8,23) it has no process-global switch.
  * The same translation unit compiled with -DCNT_TEST_HOOKS is tests/libcute_nt_hip_hooks.so (cute_nucleotides_amd/build.py
  * build_hooks; the lab build has the hooks too) -- every kernel byte-identical to the product's
@@ -374,6 +374,11 @@ int cnt_test_advise_output(void *out, size_t bytes);
  * the slab, every letter and packed dword owned by exactly one of tiles / edge items, tiles off the final partial word
  * under CNT_TAIL_LUT. */
 int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t *out);
+/* The head cnt_bits_to_n_dev would peel for buffers at these ADDRESSES (nothing is dereferenced, no device needed): out[0] =
+ * nucleotides in front of the first tile, out[1] = the first tile's output byte inside its 4-KiB page, out[2] = its packed byte
+ * inside ITS page (where every XCD turn of four tiles starts: the launcher peels up to three further output pages so that this
+ * lies within 512 bytes of a page boundary of the packed buffer), out[3] = the packed stream's bit phase. */
+int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t *out);
 #endif /* CNT_TEST_HOOKS */
 
 #ifdef __cplusplus

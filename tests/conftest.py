@@ -43,7 +43,7 @@ def lab_build():
 
 @pytest.fixture()
 def hooks_build():
-    """Run this test against tests/libcute_nt_hip_hooks.so (-DCNT_TEST_HOOKS: the product's sources and kernels plus the three
+    """Run this test against tests/libcute_nt_hip_hooks.so (-DCNT_TEST_HOOKS: the product's sources and kernels plus the
     cnt_test_* hooks).  The product library exports no hook and has no switch that could fold shards onto another device
     (VERDICT r04 next-4), so every test that needs N > 1 shards on the 1-GPU box, the huge-page advice alone or the fused
     launch plan takes this fixture; everything else runs on the product."""

@@ -52,11 +52,11 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 def test_product_exports_no_test_hook():
     """cnt_test_alias_devices / cnt_test_advise_output / cnt_test_round_trip_plan are declared under
     #ifdef CNT_TEST_HOOKS and exist only in tests/libcute_nt_hip_hooks.so (and the lab build): the product's dynamic symbol
-    table has no cnt_test_* entry, and the hooks build adds exactly those three to the product's ABI."""
+    table has no cnt_test_* entry, and the hooks build adds exactly those to the product's ABI."""
     from cute_nucleotides_amd import _lib, build
 
     hooks = _declared(hooks=True)
-    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) == ["cnt_test_advise_output", "cnt_test_alias_devices", "cnt_test_round_trip_plan"]
+    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) == ["cnt_test_advise_output", "cnt_test_alias_devices", "cnt_test_decode_plan", "cnt_test_round_trip_plan"]
     product = _exported(build.build())
     assert not [n for n in product if n.startswith("cnt_test_")], product
     assert _exported(build.build_hooks()) == sorted(product + hooks)

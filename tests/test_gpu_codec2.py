@@ -676,6 +676,41 @@ def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
         assert torch.equal(v_back[lo : lo + (1 << 28)], v_in[lo : lo + (1 << 28)]), lo
 
 
+def test_decode_turn_rotation_at_every_kind_of_packed_offset(cn, oracle, torch_cuda):
+    """Round 5: for calls of >= 2^20 nt the decoder peels 0-3 further output pages so that its XCD turns
+    start near a page boundary of the PACKED buffer (device_tier.inc decode_turn_pages; tests/test_decode_plan.py walks the
+    arithmetic).  Here the product library decodes 2^20 + a ragged bit with the packed words at offsets that make every k
+    (0..3), with the stream and the shifted kernel (output phases 0 / 16 / 5 / 77), guards around the output -- a head of up to
+    16 383 letters rides in the edge items of the same launch -- bit-exact against bits_to_n_lut."""
+    from cute_nucleotides_amd import _lib
+
+    assert not _lib.is_lab_build()
+    torch = torch_cuda
+    n_len = (1 << 20) + 4096 * 5 + 1234
+    n = _rand_valid(n_len, 81)
+    want = oracle.n_to_bits_lut(n)
+    want_back = oracle.bits_to_n_lut(want, n_len)
+    pbuf = torch.zeros(want.size + 2048, dtype=torch.int64, device="cuda")
+    obuf = torch.empty(n_len + 4 * 4096, dtype=torch.uint8, device="cuda")
+    pb = ((-pbuf.data_ptr()) % 4096) // 8  # pbuf[pb] sits on a 4-KiB page ...
+    ob = 4096 + (-obuf.data_ptr()) % 4096  # ... and so does obuf[ob], with a guard page in front of it
+    for p_off in (0, 8, 264, 512, 1016, 1024, 1032, 1544, 2048, 2056, 2824, 3072, 3080, 3592, 4088):
+        d = pbuf[pb + p_off // 8 : pb + p_off // 8 + want.size]
+        d.copy_(torch.from_numpy(want.view(np.int64)))
+        for oo in (0, 16, 5, 77, 4095):
+            obuf.fill_(0x2A)
+            cn.bits_to_n_dev(d, n_len, out=obuf[ob + oo : ob + oo + n_len])
+            got = obuf.cpu().numpy()
+            assert (got[: ob + oo] == 0x2A).all() and (got[ob + oo + n_len :] == 0x2A).all(), (p_off, oo)
+            assert np.array_equal(got[ob + oo : ob + oo + n_len], want_back), (p_off, oo)
+        # a shorter length from the same words (len < capacity), still >= 2^20
+        m = (1 << 20) + 7
+        obuf.fill_(0x2A)
+        cn.bits_to_n_dev(d, m, out=obuf[3 : 3 + m])
+        got = obuf.cpu().numpy()
+        assert (got[:3] == 0x2A).all() and (got[3 + m :] == 0x2A).all() and np.array_equal(got[3 : 3 + m], want_back[:m]), p_off
+
+
 # ---- boundary behaviour of the C ABI -------------------------------------------------------
 def test_output_pointer_only_8_byte_aligned(cn, oracle, torch_cuda):
     """u64 outputs need 8-B alignment; 16-B is only needed for the fast path."""
