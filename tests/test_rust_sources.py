@@ -87,3 +87,46 @@ def test_binding_keeps_the_reference_signatures_and_is_well_formed():
             elif ch in ")]}":
                 assert stack and "([{".index(stack.pop()) == ")]}".index(ch), rel
         assert not stack, rel
+
+
+def _split_top_level(args):
+    """split an argument list on commas that are not inside (), [], {} or <>"""
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "([{<":
+            depth += 1
+        elif ch in ")]}>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_every_ffi_call_site_passes_as_many_arguments_as_the_extern_declares():
+    """No compiler has seen rust/src/hip.rs: the one class of error a text check CAN rule out in the FFI layer is arity -- every
+    call of a `cnt_*` symbol in the wrappers hands over exactly as many arguments as its `extern "C"` declaration (which
+    tests/test_host_mirrors.py holds to the header) lists.  A wrapper that drifted when an entry point grew a parameter would
+    otherwise only be found by the first user with a toolchain."""
+    hip = open(os.path.join(ROOT, "rust", "src", "hip.rs")).read()
+    hip = re.sub(r"//[^\n]*", "", hip)
+    block = re.search(r'extern "C" \{(.*?)\n\}', hip, re.S).group(1)
+    arity = {name: len(_split_top_level(args)) for name, args in re.findall(r"fn (cnt_\w+)\((.*?)\)", block, re.S)}
+    assert len(arity) >= 35
+    body = hip.split('extern "C" {', 1)[1].split("\n}", 1)[1]
+    calls = 0
+    for m in re.finditer(r"\b(cnt_\w+)\(", body):
+        name, i = m.group(1), m.end()
+        depth, j = 1, i
+        while depth:  # the matching parenthesis
+            depth += {"(": 1, ")": -1}.get(body[j], 0)
+            j += 1
+        got = len(_split_top_level(body[i : j - 1]))
+        assert name in arity, "%s is called but not declared in the extern block" % name
+        assert got == arity[name], "%s: %d arguments at a call site, %d parameters declared: %s" % (name, got, arity[name], body[i : j - 1][:120])
+        calls += 1
+    assert calls >= 45 and set(arity) - {m.group(1) for m in re.finditer(r"\b(cnt_\w+)\(", body)} == set(), "every declared symbol is used"
