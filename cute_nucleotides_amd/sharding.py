@@ -188,7 +188,8 @@ class DevQueue:
             ms = q.wait()                               # per-shard device milliseconds of the whole batch
             enc0 = q.op_ms(0)                           # ... and of each op
 
-    The tensors handed to an enqueue call are kept alive until the next wait().  The queue's streams are the library's
+    The tensors handed to an enqueue call are kept alive until the next wait() -- wait regularly: a timed queue refuses the
+    4097th op of a batch (CNT_ECAP), an untimed one has no limit and pins everything it was handed until then.  The queue's streams are the library's
     own: whatever produced a shard on a torch stream must either be complete before the ops that read it are enqueued, or
     -- no host synchronisation -- be ordered in front of them ON THE DEVICE:
 

@@ -115,6 +115,36 @@ def test_five_letter_codec_fuzz(oracle, small_nt, seed):
         assert (d[:off_d] == 0x5A).all() and (d[off_d + length :] == 0x5A).all()
 
 
+@pytest.mark.parametrize("seed", range(2 * SEEDS))
+def test_large_decode_fuzz_over_packed_page_offsets(oracle, seed):
+    """Calls of >= 2^20 nt peel the output to a 4-KiB page and then 0-3 FURTHER pages so that the XCD turns start near a page
+    boundary of the packed buffer (round 5, device_tier.inc decode_turn_pages): random packed word offsets inside a page x
+    random output byte offsets x random lengths, the product library, guards around the output, against bits_to_n_lut."""
+    import torch
+
+    import cute_nucleotides_amd as cn
+
+    rng = np.random.default_rng(9000 + seed)
+    cap_words = ((1 << 21) + 70000) // 32
+    bits = rng.integers(0, 2**64, cap_words, dtype=np.uint64)
+    want = oracle.bits_to_n_lut(bits, cap_words * 32)
+    pbuf = torch.zeros(cap_words + 1024, dtype=torch.int64, device="cuda")
+    obuf = torch.empty(cap_words * 32 + 3 * 4096, dtype=torch.uint8, device="cuda")
+    pb = ((-pbuf.data_ptr()) % 4096) // 8
+    ob = 4096 + (-obuf.data_ptr()) % 4096
+    for _ in range(6):
+        p_off = int(rng.integers(0, 512))  # words: the packed pointer anywhere inside its page
+        o_off = int(rng.integers(0, 4096))
+        length = int(rng.integers(1 << 20, cap_words * 32 + 1))
+        d = pbuf[pb + p_off : pb + p_off + cap_words]
+        d.copy_(torch.from_numpy(bits.view(np.int64)))
+        obuf.fill_(0x5A)
+        cn.bits_to_n_dev(d, length, out=obuf[ob + o_off : ob + o_off + length])
+        got = obuf.cpu().numpy()
+        assert np.array_equal(got[ob + o_off : ob + o_off + length], want[:length]), (seed, p_off, o_off, length)
+        assert (got[: ob + o_off] == 0x5A).all() and (got[ob + o_off + length :] == 0x5A).all(), (seed, p_off, o_off, length)
+
+
 @pytest.fixture()
 def alias(hooks_build):
     """the test-hooks build with cnt_test_alias_devices(1) for one test: shard k -> device k % count on the 1-GPU box (the
