@@ -26,6 +26,13 @@
 #include <vector>
 
 #include "../cute_nucleotides_amd/cute_nucleotides.hpp"
+#if __has_include(<hip/hip_runtime_api.h>)  // built by hipcc (__graft_entry__.build()): the caller's own streams and events for the ordering row
+#ifndef __HIP_PLATFORM_AMD__
+#define __HIP_PLATFORM_AMD__ 1
+#endif
+#include <hip/hip_runtime_api.h>
+#define CNT_TWIN_HAS_HIP 1
+#endif
 
 using namespace cute_nucleotides;
 using clk = std::chrono::steady_clock;
@@ -214,6 +221,60 @@ int main(int argc, char** argv) {
         printf("%-12s %-34s time: %10.3f us   thrpt: %9.4f GiB/s  (%.3f Gnt/s)\n", "queue", "3 x (encode + decode)/2^22, one wait", total[0] * 1e3 / 6,
                len / (total[0] * 1e-3 / 6) / (double)(1ull << 30), len / (total[0] * 1e-3 / 6) / 1e9);
     }
+#ifdef CNT_TWIN_HAS_HIP
+    // ---- the queue ordered against the CALLER's streams on the device (round 5), through the C++ mirror: (a) the queue adopts
+    // the caller's stream -- upload, fused encode + decode and a device-side copy of the result all in order on it; (b) a
+    // library-stream queue waits for the caller's event behind an asynchronous upload and records one for the caller's
+    // stream to wait on.  One host synchronisation at the end of each.
+    {
+        const size_t len = (size_t)1 << 22;
+        const auto n = repeat("ATCG", len / 4);
+        device::set_device(0);
+        device::DeviceBuffer d_n(len), d_bits(len / 4), d_back(len), d_copy(len);
+        hipStream_t st = nullptr;
+        hipEvent_t filled = nullptr, done = nullptr;
+        void* pinned = nullptr;
+        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&filled) == hipSuccess &&
+                  hipEventCreate(&done) == hipSuccess && hipHostMalloc(&pinned, len, hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            fprintf(stderr, "stream / event / pinned setup failed\n");
+            return 2;
+        }
+        memcpy(pinned, n.data(), len);
+        const auto t0 = std::chrono::steady_clock::now();
+        {   // (a) adopted stream
+            ok = ok && hipMemcpyAsync(d_n.data(), pinned, len, hipMemcpyHostToDevice, st) == hipSuccess;
+            device::ShardedDevQueue q(std::vector<void*>{st});
+            q.enqueue_round_trip({&d_n}, {len}, {&d_bits}, {&d_back});
+            ok = ok && hipMemcpyAsync(d_copy.data(), d_back.data(), len, hipMemcpyDeviceToDevice, st) == hipSuccess;
+            ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        }   // the queue is gone, the caller's stream is not
+        ok = ok && d_copy.to_vector<uint8_t>(len) == n;
+        for (uint64_t w : d_bits.to_vector<uint64_t>(len / 32)) ok = ok && w == 0xD8D8D8D8D8D8D8D8ull;
+        {   // (b) events
+            ok = ok && hipMemsetAsync(d_n.data(), 'G', len, st) == hipSuccess && hipMemsetAsync(d_copy.data(), 0, len, st) == hipSuccess;
+            ok = ok && hipEventRecord(filled, st) == hipSuccess;
+            device::ShardedDevQueue q(1);
+            q.wait_event(0, filled);
+            q.enqueue_n_to_bits({&d_n}, {len}, {&d_bits});
+            q.enqueue_bits_to_n({&d_bits}, {len / 32}, {len}, {&d_back});
+            q.record_event(0, done);
+            ok = ok && hipStreamWaitEvent(st, done, 0) == hipSuccess;
+            ok = ok && hipMemcpyAsync(d_copy.data(), d_back.data(), len, hipMemcpyDeviceToDevice, st) == hipSuccess;
+            ok = ok && hipStreamSynchronize(st) == hipSuccess;
+            q.wait();
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        ok = ok && d_copy.to_vector<uint8_t>(len) == std::vector<uint8_t>(len, (uint8_t)'G');
+        for (uint64_t w : d_bits.to_vector<uint64_t>(len / 32)) ok = ok && w == ~0ull;  // G = 11
+        (void)hipEventDestroy(filled); (void)hipEventDestroy(done); (void)hipHostFree(pinned); (void)hipStreamDestroy(st);
+        if (!ok) {
+            fprintf(stderr, "ShardedDevQueue ordering mismatch\n");
+            return 2;
+        }
+        printf("%-12s %-34s time: %10.3f us   thrpt: %9.4f GiB/s\n", "queue", "adopted stream + events/2^22", us / 2, len / (us * 1e-6 / 2) / (double)(1ull << 30));
+    }
+#endif
     cnt_shutdown();
     printf("self-check ok: every C-ABI row reproduced its input (host tier, reused outputs, device tier)\n");
     return 0;

@@ -187,8 +187,8 @@ int cnt_bits_to_n2_sharded_dev(const void *const *d_bits, const size_t *words, c
  *   cnt_sharded_dev_record_event  records the caller's hipEvent_t (created on shard k's device) on shard k's stream: it
  *                                 completes when everything enqueued for shard k so far has.  A consumer stream that
  *                                 hipStreamWaitEvent()s on it reads the outputs without any host synchronisation.
- *   cnt_sharded_dev_open_on_streams  the queue ADOPTS the caller's streams instead of creating its own: streams[k] is a
- *                                 hipStream_t of device k (never NULL: the legacy default stream synchronises with
+ *   cnt_sharded_dev_open_on_streams  the queue ADOPTS the caller's streams instead of creating its own: ndev >= 1 entries,
+ *                                 streams[k] is a hipStream_t of device k (never NULL: the legacy default stream synchronises with
  *                                 everything), shard k's ops are enqueued on it, in order with whatever the caller puts
  *                                 on that stream before and after -- the ordering the single-GPU *_dev entry points have
  *                                 by taking the caller's stream.  close() neither synchronises nor destroys adopted

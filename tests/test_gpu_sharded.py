@@ -490,6 +490,7 @@ def test_queue_ordering_entry_points_error_paths_and_the_timed_op_cap(L, alias):
     assert L.cnt_sharded_dev_open_on_streams(2, None, 0, ctypes.byref(q)) == _lib.CNT_EINVAL
     assert L.cnt_sharded_dev_open_on_streams(2, (ctypes.c_void_p * 2)(st[0].cuda_stream, None), 0, ctypes.byref(q)) == _lib.CNT_EINVAL  # never the legacy default stream
     assert L.cnt_sharded_dev_open_on_streams(65, two, 0, ctypes.byref(q)) == _lib.CNT_ENODEV
+    assert L.cnt_sharded_dev_open_on_streams(0, two, 0, ctypes.byref(q)) == _lib.CNT_EINVAL  # the array's length IS ndev: "all devices" means nothing here
     assert L.cnt_sharded_dev_open_on_streams(2, two, 0, ctypes.byref(q)) == 0 and q.value
     ev = torch.cuda.Event()
     ev.record()
