@@ -63,7 +63,13 @@ cases = [(0, p) for p in packed] + [(16, p) for p in packed] + [(5, p) for p in 
 if a.quick:
     cases = [(0, 0), (0, 8), (0, 1032), (0, 2056), (16, 8), (16, 264), (16, 2312), (5, 264)]
 
-MODES = (("k0", 0, 0), ("k1", 0, 1), ("k2", 0, 2), ("k3", 0, 3), ("after", 0, 10), ("nearest", 0, 11), ("shipped", 0, -1), ("plain", 42, -1))
+# (name, decode variant, decode_rot, decode_window): round 4's kernels (stream at any dword phase, shifted for a bit phase) with
+# k further pages / the two rules; round 5's window kernel (line-aligned 16-B loads + a funnel read of the wave's slab) with no
+# turn placement, with the rule forced, and as shipped (the rule from 2^30 nt on); plain dispatch order
+MODES = (("k0", 0, 0, 0), ("k1", 0, 1, 0), ("k2", 0, 2, 0), ("k3", 0, 3, 0), ("after", 0, 10, 0), ("nearest", 0, 11, 0),
+         ("window_k0", 0, 0, 1), ("window_nearest", 0, 11, 1), ("shipped", 0, -1, 1), ("plain", 42, 0, 0))
+if os.environ.get("CNT_OFF_GRID_FEW_MODES") == "1":  # size sweeps: the four that matter
+    MODES = tuple(m for m in MODES if m[0] in ("k0", "nearest", "window_k0", "shipped"))
 for a_off, p_off in cases:
     d_out = b_out[a_off : a_off + n]
     d_pk = b_pk[p_off // 8 : p_off // 8 + n // 32]
@@ -72,28 +78,31 @@ for a_off, p_off in cases:
     r0 = (base_pk + p_off + 4 * (head >> 4)) % 4096
     row = {"ascii_off": a_off, "packed_off": p_off, "kernel": "stream" if head % 16 == 0 else "shifted", "r": r0,
            "r_k": [(r0 + 1024 * k) % 4096 for k in range(4)], "k_after": (4 - (r0 >> 10)) & 3, "k_nearest": (4 - ((r0 + 512) >> 10)) & 3}
-    ms = {name: [] for name, _, _ in MODES}
+    ms = {m[0]: [] for m in MODES}
 
     def call():
         cn.bits_to_n_dev(d_pk, n, out=d_out)
 
-    for name, variant, rot in MODES:  # warm every mode once (and check it)
+    def select(variant, rot, window):
         devutil.set_tuning("decode", variant)
         devutil.set_tuning("decode_rot", rot)
+        devutil.set_tuning("decode_window", window)
+
+    for name, variant, rot, window in MODES:  # warm every mode once
+        select(variant, rot, window)
         call()
     torch.cuda.synchronize()
     for rnd in range(a.rounds):
         order = MODES if rnd % 2 == 0 else MODES[::-1]  # alternate the order: a drift does not favour one mode
-        for name, variant, rot in order:
-            devutil.set_tuning("decode", variant)
-            devutil.set_tuning("decode_rot", rot)
+        for name, variant, rot, window in order:
+            select(variant, rot, window)
             ms[name].append(once(call, a.it))
-    for name, _, _ in MODES:
-        row[name] = round(1.25 * n / statistics.median(ms[name]) / 1e6, 1)
-        row[name + "_best"] = round(1.25 * n / min(ms[name]) / 1e6, 1)
-    devutil.set_tuning("decode", 0)
-    devutil.set_tuning("decode_rot", 3)  # the largest head: 3 pages + the peel, all through the edge items
-    call()
-    assert devutil.count_mismatch(b_in[:n].contiguous(), d_out.contiguous()) == 0, (a_off, p_off)
-    devutil.set_tuning("decode_rot", -1)
+    for m in MODES:
+        row[m[0]] = round(1.25 * n / statistics.median(ms[m[0]]) / 1e6, 1)
+        row[m[0] + "_best"] = round(1.25 * n / min(ms[m[0]]) / 1e6, 1)
+    for variant, rot, window in ((0, 3, 1), (0, 3, 0), (0, -1, 1)):  # the largest heads through the edge items, both kernel families; then as shipped
+        select(variant, rot, window)
+        d_out.zero_()
+        call()
+        assert devutil.count_mismatch(b_in[:n].contiguous(), d_out.contiguous()) == 0, (a_off, p_off, rot, window)
     print(json.dumps(row), flush=True)

@@ -235,23 +235,64 @@ __device__ __forceinline__ void encode_edges(const EncodeEdges& e, uint64_t idx,
 }
 inline uint64_t encode_edge_items(const EncodeEdges& e) { return e.head_words + (e.words - e.tail_first); }
 
-// nucleotides [0, head) and [tail_lo, len) of a decode, one thread per nucleotide (byte stores:
-// the head exists because the output pointer is NOT aligned)
+// nucleotides [0, head) and [tail_lo, len) of a decode.  The head exists because the output pointer is NOT aligned -- but
+// only its first <= 15 letters are: from the first 16-B boundary of the output on, head and tail are spelled 16 letters per
+// work item (two packed dwords through v_alignbit_b32, one 16-B store), and only the few letters in front of that boundary
+// and behind the last whole 16 go one per item.  (Round 5: a head of up to 4 095 + 4 x 4 096 letters -- the peel to a page,
+// the pages that place the XCD turns, the pages that keep the window kernel's reads inside the buffer -- was up to 20 479
+// byte items shared by 4 096 threads: microseconds behind a 10-40 us kernel, -2 % per page at 2^26-2^28 nt.)
 struct DecodeEdges {
     const uint64_t* bits;
     uint8_t* out;
     uint64_t head, tail_lo, len;
     uint32_t groups;  // as in EncodeEdges
 };
+// how the edge items are laid out: a byte items, nv 16-letter items of the head, nvt of the tail, rb byte items behind them
+struct DecodeEdgeLayout {
+    uint64_t a, nv, nvt, rb;
+};
+__host__ __device__ __forceinline__ DecodeEdgeLayout decode_edge_layout(const DecodeEdges& e) {
+    DecodeEdgeLayout l;
+    const uint64_t to16 = (16 - (reinterpret_cast<uintptr_t>(e.out) & 15)) & 15;
+    l.a = e.head < to16 ? e.head : to16;
+    l.nv = (e.head - l.a) >> 4;
+    if ((e.head - l.a) & 15) {  // a head that does not end on a 16-B boundary of the output (never the launchers'): all bytes
+        l.a = e.head;
+        l.nv = 0;
+    }
+    const uint64_t tail = e.len - e.tail_lo;
+    const bool tail_vec = ((reinterpret_cast<uintptr_t>(e.out) + e.tail_lo) & 15) == 0;
+    l.nvt = tail_vec ? tail >> 4 : 0;
+    l.rb = tail - (l.nvt << 4);
+    return l;
+}
+__device__ __forceinline__ void decode_edge_letter(const DecodeEdges& e, uint64_t i) {
+    const uint32_t code = (uint32_t)(e.bits[i >> 5] >> ((i & 31) << 1)) & 3u;
+    e.out[i] = (uint8_t)(0x47544341u >> (code << 3));  // "ACTG"[code], n_to_bits.rs:23-30
+}
+// 16 letters from nucleotide n0 on (out + n0 on a 16-B boundary, n0 + 16 <= len): the second dword is only touched when it
+// holds some of these letters' bits, so nothing behind the caller's `len` is read
+__device__ __forceinline__ void decode_edge_vector(const DecodeEdges& e, uint64_t n0) {
+    const uint32_t* dw = reinterpret_cast<const uint32_t*>(e.bits) + (n0 >> 4);
+    const uint32_t sh = 2u * (uint32_t)(n0 & 15);
+    const uint32_t lo = dw[0], hi = sh ? dw[1] : 0u;
+    *reinterpret_cast<u32x4*>(e.out + n0) = dec4(__builtin_amdgcn_alignbit(hi, lo, sh));
+}
 __device__ __forceinline__ void decode_edges(const DecodeEdges& e, uint64_t idx, uint64_t stride) {
-    const uint64_t items = e.head + (e.len - e.tail_lo);
+    const DecodeEdgeLayout l = decode_edge_layout(e);
+    const uint64_t head_first_vec = l.a;
+    const uint64_t items = l.a + l.nv + l.nvt + l.rb;
     for (uint64_t k = idx; k < items; k += stride) {
-        const uint64_t i = k < e.head ? k : e.tail_lo + (k - e.head);
-        const uint32_t code = (uint32_t)(e.bits[i >> 5] >> ((i & 31) << 1)) & 3u;
-        e.out[i] = (uint8_t)(0x47544341u >> (code << 3));  // "ACTG"[code], n_to_bits.rs:23-30
+        if (k < l.a) decode_edge_letter(e, k);
+        else if (k < l.a + l.nv) decode_edge_vector(e, head_first_vec + ((k - l.a) << 4));
+        else if (k < l.a + l.nv + l.nvt) decode_edge_vector(e, e.tail_lo + ((k - l.a - l.nv) << 4));
+        else decode_edge_letter(e, e.tail_lo + (l.nvt << 4) + (k - l.a - l.nv - l.nvt));
     }
 }
-inline uint64_t decode_edge_items(const DecodeEdges& e) { return e.head + (e.len - e.tail_lo); }
+inline uint64_t decode_edge_items(const DecodeEdges& e) {
+    const DecodeEdgeLayout l = decode_edge_layout(e);
+    return l.a + l.nv + l.nvt + l.rb;
+}
 
 // the ragged end of a fused round trip: words [tail_first, words) with their letters -- a thread packs one word from
 // byte loads and spells the same codes back out (no thread waits for another's word)
@@ -586,6 +627,49 @@ __global__ __launch_bounds__(BLOCK) void bits_to_n_shifted(const uint8_t* __rest
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x[u])), rout, (u * BLOCK + tid) * 16, 0, SAUX);
     CNT_DECODE_EDGES_TAIL(BLOCK)
+}
+
+// WINDOW (round 5): output tile-aligned, the packed stream entered at ANY bit position -- off its 128-B lines included --
+// with every global load line-aligned.  bits_to_n_stream's four 4-B loads per lane cover 256 B per wave-instruction; when
+// the packed pointer is not on a line each of them straddles THREE lines instead of two (3-6 % of the kernel, whatever the
+// XCD turns do: profiles/r05_decode_off_grid.md), and bits_to_n_shifted doubles them for the bit phase.  Here the wave
+// loads the 128-B-aligned window over its tile's 1 KiB of packed words as ONE 16-B load per lane (eight whole lines per
+// wave-instruction) plus, for the lanes that reach that far, the <= 8 vectors behind it (the others aim past the
+// descriptor's range: zeros, no memory access -- branch-free, round_trip_window's trick), parks the dwords in its slab --
+// the dynamic LDS that caps residency -- and every lane funnel-reads its four packed dwords at the stream's phase: dword
+// phase q (0..31), bit phase sh (0..30, even).  `in` = the window of tile 0 (128-B aligned, inside the caller's buffer: the
+// launcher sees to both ends).
+constexpr uint32_t kWindowDecodeTile = 64 * 4 * 16;
+constexpr uint32_t kWindowDecodeSlack = 9 * 16;        // bytes a tile may read behind its 1 KiB: (31 + 1 + 3) / 4 vectors, rounded up
+constexpr uint32_t kWindowDecodeSlab = 2 * 64 * 4 * 4;  // LDS bytes: the tile's 256 dwords + one row behind them
+template <int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(kWave) void bits_to_n_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t q,
+                                                          uint32_t sh, uint32_t xs, DecodeEdges e) {
+    constexpr uint32_t TILE_OUT = kWindowDecodeTile, TILE_IN = TILE_OUT / 4;
+    const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
+    const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + kWindowDecodeSlack);
+    const __amdgpu_buffer_rsrc_t rout = rsrc_of(out + t * TILE_OUT, TILE_OUT);
+    const uint32_t lane = threadIdx.x;
+    // the funnels reach dword 255 + q, and 256 + q with a bit phase: ceil((q + (sh != 0)) / 4) vectors behind the tile's 64
+    const uint32_t extra = (q + (sh ? 1u : 0u) + 3u) >> 2;
+    const u32x4 v0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, LAUX));
+    const u32x4 v1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane < extra ? TILE_IN + lane * 16 : 0xFFFFFF00u, 0, LAUX));
+    residency_pad[4 * lane + 0] = v0.x;
+    residency_pad[4 * lane + 1] = v0.y;
+    residency_pad[4 * lane + 2] = v0.z;
+    residency_pad[4 * lane + 3] = v0.w;
+    residency_pad[256 + 4 * lane + 0] = v1.x;
+    residency_pad[256 + 4 * lane + 1] = v1.y;
+    residency_pad[256 + 4 * lane + 2] = v1.z;
+    residency_pad[256 + 4 * lane + 3] = v1.w;
+    wave_lds_fence();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t j = u * kWave + lane + q;
+        const uint32_t x = __builtin_amdgcn_alignbit(residency_pad[j + 1], residency_pad[j], sh);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(x)), rout, (u * kWave + lane) * 16, 0, SAUX);
+    }
+    CNT_DECODE_EDGES_TAIL(kWave)
 }
 
 // LDS (measured alternative): each wave loads U/4 x 1 KiB of packed words as

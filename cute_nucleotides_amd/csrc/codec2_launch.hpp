@@ -450,8 +450,9 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     return 0;
 }
 
-// The any-alignment companion of decode variant 0: `in` = the dword holding the first
-// nucleotide, `sh` = 2 * (its index among that dword's 16).
+#ifdef CNT_LAB_VARIANTS
+// Round 4's any-phase companion of decode variant 0 (lab build only since round 5: bits_to_n_window took its place): `in` =
+// the dword holding the first nucleotide, `sh` = 2 * (its index among that dword's 16).
 constexpr uint32_t kShiftedDecodeTile = 64 * 4 * 16;
 inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, DecodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64);
@@ -463,6 +464,24 @@ inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, 
         e.groups = first + n_tiles == total_tiles ? edge_groups(decode_edge_items(e), 64, n_tiles) : 0u;
         hipLaunchKernelGGL((bits_to_n_shifted<64, 4, 4, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, (uint32_t)n_tiles, sh, xs, e);
+    }
+}
+#endif
+
+// The window decoder (codec2_kernels.hpp, bits_to_n_window): `window` = the 128-B-aligned address at or in front of the dword
+// that holds the tile sequence's first nucleotide, q = that dword's index in the window (0..31), sh = 2 * (the nucleotide's
+// index among the dword's 16).  Same map, policies and residency cap as the stream kernel; the cap's dynamic LDS doubles as
+// the 2-KiB slab.
+inline void launch_decode_window(const uint8_t* window, uint32_t q, uint32_t sh, uint8_t* out, uint64_t total_tiles, DecodeEdges e, hipStream_t s) {
+    const uint64_t per_launch = max_tiles_per_launch(64);
+    const uint32_t lds = std::max(lds_for_cap(14), kWindowDecodeSlab);
+    const uint32_t xs = xcd_shift();
+    e.tail_lo = e.head + total_tiles * kWindowDecodeTile;
+    for (uint64_t first = 0; first < total_tiles; first += per_launch) {
+        const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
+        e.groups = first + n_tiles == total_tiles ? edge_groups(decode_edge_items(e), 64, n_tiles) : 0u;
+        hipLaunchKernelGGL((bits_to_n_window<4, 0, kSC0 | kSC1 | kNT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+                           window + first * (kWindowDecodeTile / 4), out + first * kWindowDecodeTile, (uint32_t)n_tiles, q, sh, xs, e);
     }
 }
 

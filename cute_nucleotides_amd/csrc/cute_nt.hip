@@ -101,6 +101,8 @@ std::atomic<int> g_round_trip_plan{kRoundTripDefaultPlan};  // pricing of the an
 inline int tune_round_trip_plan() { return g_round_trip_plan.load(std::memory_order_relaxed); }
 std::atomic<int> g_decode_rot{-1};  // further 4-KiB output pages peeled in front of decode's tiles (device_tier.inc decode_turn_pages): -1 the shipped rule, 0..3 forced, 10 / 11 the two candidate rules
 inline int tune_decode_rot() { return g_decode_rot.load(std::memory_order_relaxed); }
+std::atomic<int> g_decode_window{1};  // 1 (shipped): bits_to_n_window whenever the packed stream is off its lines or dwords; 0: round 4's stream / shifted kernels
+inline bool tune_decode_window() { return g_decode_window.load(std::memory_order_relaxed) != 0; }
 #else
 constexpr int tune_encode() { return 0; }
 constexpr int tune_decode() { return 0; }
@@ -112,6 +114,7 @@ constexpr uint32_t tune_round_trip_cap() { return kRoundTripDefaultCap; }
 constexpr int tune_round_trip_window_map() { return 0; }
 constexpr int tune_round_trip_plan() { return kRoundTripDefaultPlan; }
 constexpr int tune_decode_rot() { return -1; }
+constexpr bool tune_decode_window() { return true; }
 #endif
 
 inline unsigned generic_grid(uint64_t items) {
@@ -458,6 +461,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "round_trip_plan")) {
         if (value < 0 || value > 3) return CNT_EINVAL;
         g_round_trip_plan.store(value);
+    } else if (!strcmp(key, "decode_window")) {
+        if (value < 0 || value > 1) return CNT_EINVAL;
+        g_decode_window.store(value);
     } else if (!strcmp(key, "decode_rot")) {
         if (value < -1 || (value > 3 && value != 10 && value != 11)) return CNT_EINVAL;
         g_decode_rot.store(value);
@@ -512,6 +518,7 @@ int cnt_get_tuning(const char* key, int* value) {
 #ifdef CNT_LAB_VARIANTS
     else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
     else if (!strcmp(key, "decode_rot")) *value = g_decode_rot.load();
+    else if (!strcmp(key, "decode_window")) *value = g_decode_window.load();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "hamming_order")) *value = g_hamming_order.load();
     else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
@@ -594,11 +601,14 @@ int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uin
 }
 int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t* out) {
     if (!out || (a_bits & 7)) return CNT_EINVAL;
-    const uint64_t head = decode_head((uintptr_t)a_bits, (uintptr_t)a_out, len, tune_decode_rot());
-    out[0] = head;                                   // nucleotides in front of the first tile (edge items)
-    out[1] = (a_out + head) & 4095;                  // the first tile's output byte inside its page (0 for len >= 2^20)
-    out[2] = (a_bits + 4 * (head >> 4)) & 4095;      // the first tile's packed byte inside its page: where every XCD turn starts
-    out[3] = 2 * (head & 15);                        // bit phase of the packed stream (0: bits_to_n_stream, else bits_to_n_shifted)
+    const DecodePlan p = decode_plan((uintptr_t)a_bits, (uintptr_t)a_out, len, tune_decode_rot(), tune_decode_window());
+    out[0] = p.head;                                   // nucleotides in front of the first tile (edge items)
+    out[1] = (a_out + p.head) & 4095;                  // the first tile's output byte inside its page (0 for len >= 2^20)
+    out[2] = (a_bits + 4 * (p.head >> 4)) & 4095;      // the first tile's packed byte inside its page: where every XCD turn starts
+    out[3] = p.sh;                                     // bit phase of the packed stream
+    out[4] = p.q;                                      // dword phase against the 128-B line
+    out[5] = p.window ? 1 : 0;                         // bits_to_n_window (else bits_to_n_stream)
+    out[6] = p.tiles;
     return CNT_OK;
 }
 int cnt_test_advise_output(void* out, size_t bytes) {

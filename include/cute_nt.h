@@ -374,10 +374,12 @@ int cnt_test_advise_output(void *out, size_t bytes);
  * the slab, every letter and packed dword owned by exactly one of tiles / edge items, tiles off the final partial word
  * under CNT_TAIL_LUT. */
 int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t *out);
-/* The head cnt_bits_to_n_dev would peel for buffers at these ADDRESSES (nothing is dereferenced, no device needed): out[0] =
+/* The launch plan cnt_bits_to_n_dev would use for buffers at these ADDRESSES (nothing is dereferenced, no device needed): out[0] =
  * nucleotides in front of the first tile, out[1] = the first tile's output byte inside its 4-KiB page, out[2] = its packed byte
- * inside ITS page (where every XCD turn of four tiles starts: the launcher peels up to three further output pages so that this
- * lies within 512 bytes of a page boundary of the packed buffer), out[3] = the packed stream's bit phase. */
+ * inside ITS page (where every XCD turn of four tiles starts: for calls of more than 2^30 nt the launcher peels up to three
+ * further output pages so that this lies within 512 bytes of a page boundary of the packed buffer), out[3] = the packed
+ * stream's bit phase, out[4] = its dword phase against the 128-byte line, out[5] = 1 if the window kernel takes the call
+ * (either phase non-zero), out[6] = whole tiles.  out holds 7 entries. */
 int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t *out);
 #endif /* CNT_TEST_HOOKS */
 
