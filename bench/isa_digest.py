@@ -28,7 +28,8 @@ SHIPPED = [
     ("encode", "void cnt::n_to_bits_stream<64, 2, 1, 2, 19, false>"),
     ("encode, any input phase", "void cnt::n_to_bits_window<4, 1, 2, 19, false>"),
     ("decode", "void cnt::bits_to_n_stream<64, 4, 4, 0, 19>"),
-    ("decode, any packed phase", "void cnt::bits_to_n_window<4, 0, 19>"),
+    ("decode, any output phase", "void cnt::bits_to_n_shifted<64, 4, 4, 0, 19>"),
+    ("decode, any packed phase past the Infinity Cache", "void cnt::bits_to_n_window<4, 0, 19>"),
     ("fused round trip", "void cnt::round_trip_stream<64, 4, 1, 2, 19, false>"),
     ("fused round trip, any alignment", "void cnt::round_trip_window<1, 2, 19, false>"),
     ("5-letter encode", "void cnt::n_to_bits2_wave<1, 2, 2, 16, false, 1>"),

@@ -321,6 +321,8 @@ __device__ __forceinline__ void round_trip_edges(const RoundTripEdges& e, uint64
 #define CNT_DECODE_EDGES_TAIL(BLOCK_)                                                                                   \
     if (blockIdx.x + e.groups >= n_tiles)                                                                               \
         decode_edges(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * (BLOCK_) + threadIdx.x, (uint64_t)e.groups * (BLOCK_));
+// (Round 5 also tried the launch's FIRST workgroups for the edge items, so that their one extra trip to memory overlaps with the
+// rest of the grid instead of ending it: +-1-4 % either way at 2^22-2^26 nt, +-0.2 % from 2^28 on -- noise; not adopted.)
 
 // ===========================================================================
 // ENCODE.  One workgroup = one tile of BLOCK*U*16 nt, no loop: the launch has one

@@ -450,9 +450,8 @@ inline int launch_decode(int variant, const void* d_bits, void* d_out, uint64_t 
     return 0;
 }
 
-#ifdef CNT_LAB_VARIANTS
-// Round 4's any-phase companion of decode variant 0 (lab build only since round 5: bits_to_n_window took its place): `in` =
-// the dword holding the first nucleotide, `sh` = 2 * (its index among that dword's 16).
+// The any-bit-phase companion of decode variant 0 for calls INSIDE the Infinity Cache (<= 2^30 nt; larger ones take
+// bits_to_n_window): `in` = the dword holding the first nucleotide, `sh` = 2 * (its index among that dword's 16).
 constexpr uint32_t kShiftedDecodeTile = 64 * 4 * 16;
 inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, uint64_t total_tiles, DecodeEdges e, hipStream_t s) {
     const uint64_t per_launch = max_tiles_per_launch(64);
@@ -466,7 +465,6 @@ inline void launch_decode_shifted(const uint8_t* in, uint32_t sh, uint8_t* out, 
                            in + first * (kShiftedDecodeTile / 4), out + first * kShiftedDecodeTile, (uint32_t)n_tiles, sh, xs, e);
     }
 }
-#endif
 
 // The window decoder (codec2_kernels.hpp, bits_to_n_window): `window` = the 128-B-aligned address at or in front of the dword
 // that holds the tile sequence's first nucleotide, q = that dword's index in the window (0..31), sh = 2 * (the nucleotide's

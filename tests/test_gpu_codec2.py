@@ -711,6 +711,45 @@ def test_decode_turn_rotation_at_every_kind_of_packed_offset(cn, oracle, torch_c
         assert (got[:3] == 0x2A).all() and (got[3 + m :] == 0x2A).all() and np.array_equal(got[3 : 3 + m], want_back[:m]), p_off
 
 
+def test_decode_past_the_infinity_cache_off_the_grid(cn, oracle, torch_cuda, fullsize):
+    """Calls of more than 2^30 nt whose packed pointer is off its 128-B lines / dwords take bits_to_n_window, and their XCD
+    turns are placed on the packed buffer's pages by peeling 0-3 (+4) further output pages (round 5, device_tier.inc
+    decode_plan; tests/test_decode_plan.py walks the arithmetic).  2^30 + a ragged bit nucleotides of seeded random ACGT,
+    encoded by the aligned call, then decoded from packed words at offsets that make every k, with dword phases (stream of
+    words at byte offsets 8 ... 4088), bit phases (output offsets 5, 77) and a head of up to 5 pages riding in the edge
+    items: the decoded text equals the input on the device, guards around it survive, and sampled chunks equal
+    bits_to_n_lut of the host-regenerated input."""
+    from conftest import need_free_hbm
+
+    from cute_nucleotides_amd import _lib, devutil
+
+    assert not _lib.is_lab_build()
+    torch = torch_cuda
+    need_free_hbm(4)
+    n_len = (1 << 30) + 4096 * 7 + 1234
+    d_in = torch.empty(n_len, dtype=torch.uint8, device="cuda")
+    devutil.fill_random_acgt(d_in, 41)
+    words = (n_len + 31) // 32
+    pbuf = torch.zeros(words + 1024, dtype=torch.int64, device="cuda")
+    obuf = torch.empty(n_len + 3 * 4096, dtype=torch.uint8, device="cuda")
+    pb = ((-pbuf.data_ptr()) % 4096) // 8
+    ob = 4096 + (-obuf.data_ptr()) % 4096
+    chunk = 1 << 20
+    ms = None
+    for p_off, o_off in ((8, 0), (264, 0), (1032, 16), (2056, 5), (3080, 77), (4088, 4095), (1024, 0), (520, 2048)):
+        d_pk = pbuf[pb + p_off // 8 : pb + p_off // 8 + words]
+        cn.n_to_bits_dev(d_in, out=d_pk)
+        obuf.fill_(0x2A)
+        view = obuf[ob + o_off : ob + o_off + n_len]
+        _, ms = _timed_ms(torch, lambda: cn.bits_to_n_dev(d_pk, n_len, out=view))
+        assert devutil.count_mismatch(d_in, view) == 0, (p_off, o_off)
+        assert bool((obuf[: ob + o_off] == 0x2A).all()) and bool((obuf[ob + o_off + n_len :] == 0x2A).all()), (p_off, o_off)
+        for lo in (0, (n_len // 2) // 32 * 32, n_len - chunk):  # head, middle, ragged end against the oracle
+            host = oracle.fill_random_acgt(chunk + 32, 41, first_nt=lo // 32 * 32)[lo % 32 : lo % 32 + chunk]
+            assert np.array_equal(view[lo : lo + chunk].cpu().numpy(), host), (p_off, o_off, lo)
+    fullsize(30, ms, config="decode off the grid past the Infinity Cache (window kernel + turn placement)", nt=n_len)
+
+
 # ---- boundary behaviour of the C ABI -------------------------------------------------------
 def test_output_pointer_only_8_byte_aligned(cn, oracle, torch_cuda):
     """u64 outputs need 8-B alignment; 16-B is only needed for the fast path."""
