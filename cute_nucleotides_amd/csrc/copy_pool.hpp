@@ -39,12 +39,21 @@ class CopyPool {
     // condition variable -- inside a pipelined call it never sleeps, so a copy starts within a microsecond instead of the
     // 20-50 us of a condition-variable wake-up (which made 8 threads SLOWER than 4 in the first version of this pool).
     void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false) {
-        // small copies never start (or wake) the team: below kMinPar always the caller's memcpy; up to kSmallCopy (the band
-        // the zero-copy small calls fall into) only a team that is ALREADY running is joined -- an isolated mid-size call
-        // must not pay for creating up to seven threads that then spin for 150 us each
-        if (bytes < kMinPar || (bytes <= kSmallCopy && !started_)) {
+        // small copies never wake a sleeping team, and an ISOLATED one never starts it: below kMinPar always the caller's
+        // memcpy; up to kSmallCopy (the band the zero-copy small calls fall into) a team that is already running is joined,
+        // and one that is not is started only by the SECOND such copy within kStreakUs -- a loop of mid-size calls, where the
+        // spinning helpers take 16 % off a 2^20-nt decode (profiles/r04_host_small_copies.md) -- so that a lone mid-size
+        // call does not pay for creating up to seven threads that then spin for 150 us each
+        if (bytes < kMinPar) {
             memcpy(dst, src, bytes);
             return;
+        }
+        if (bytes <= kSmallCopy && !started_) {
+            if (std::chrono::steady_clock::now() - last_mid_copy_ >= std::chrono::microseconds(kStreakUs)) {
+                memcpy(dst, src, bytes);
+                last_mid_copy_ = std::chrono::steady_clock::now();  // the END of this copy: the streak is the gap between calls
+                return;
+            }
         }
         const int all = threads();
         const int T = fresh_pages ? all : std::max(1, (all + 1) / 2);  // warm copies use the configured team, fresh ones twice that
@@ -122,7 +131,7 @@ class CopyPool {
     // faults a transparent huge page in instead of eight fighting over it (1-GiB decode into a fresh buffer 35 -> 24 ms).
     static constexpr size_t kMinPar = (size_t)512 << 10, kWarmBlock = (size_t)1 << 20, kFreshBlock = (size_t)2 << 20;
     static constexpr size_t kSmallCopy = (size_t)1 << 20, kSmallBlock = (size_t)256 << 10;
-    static constexpr int kSpinUs = 150;
+    static constexpr int kSpinUs = 150, kStreakUs = 2000;
     static void cpu_relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -201,4 +210,5 @@ class CopyPool {
     std::atomic<bool> stop_{false};
     int n_threads_ = 1, team_ = 1, limit_ = 0;
     bool started_ = false;
+    std::chrono::steady_clock::time_point last_mid_copy_{};  // when the calling thread's previous lone mid-size copy ended (a pool has one caller)
 };

@@ -88,13 +88,22 @@ int main(int argc, char** argv) {
         printf("ok stall\n");
         return 0;
     }
-    {  // a copy of 512 KiB .. 1 MiB never STARTS the team (it only joins one that is running already)
+    {  // an ISOLATED copy of 512 KiB .. 1 MiB never starts the team; the second one of a streak does; a running team is joined
         std::vector<uint8_t> src((size_t)4 << 20, 0x33), dst((size_t)4 << 20, 0);
+        {
+            CopyPool pool;
+            pool.copy(dst.data(), src.data(), (size_t)768 << 10, false);
+            if (pool.spawned() != 0) { printf("FAILED: a lone mid-size copy started %d helper threads\n", pool.spawned()); return 1; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));  // longer than a streak: the next one is isolated again
+            pool.copy(dst.data(), src.data(), (size_t)1 << 20, true);
+            const int after_two = pool.spawned();
+            pool.copy(dst.data() + (2 << 20), src.data(), (size_t)1 << 20, false);  // right behind the previous one: a loop of mid-size calls
+            const int after_three = pool.spawned();
+            if (after_two != 0 || memcmp(dst.data(), src.data(), (size_t)1 << 20) != 0) { printf("FAILED: two isolated mid-size copies started %d helper threads\n", after_two); return 1; }
+            if (after_three < 1 || memcmp(dst.data() + (2 << 20), src.data(), (size_t)1 << 20) != 0) { printf("FAILED: a streak of mid-size copies did not start the team\n"); return 1; }
+        }
         CopyPool pool;
-        pool.copy(dst.data(), src.data(), (size_t)768 << 10, false);
-        pool.copy(dst.data(), src.data(), (size_t)1 << 20, true);
-        if (pool.spawned() != 0 || memcmp(dst.data(), src.data(), (size_t)1 << 20) != 0) { printf("FAILED: a mid-size copy started %d helper threads\n", pool.spawned()); return 1; }
-        pool.copy(dst.data(), src.data(), (size_t)3 << 20, false);  // a large copy does
+        pool.copy(dst.data(), src.data(), (size_t)3 << 20, false);  // a large copy starts it at once
         const int team = pool.spawned();
         pool.copy(dst.data() + 5, src.data(), (size_t)768 << 10, false);  // ... and a mid-size one joins it
         if (team < 1 || pool.spawned() != team || memcmp(dst.data() + 5, src.data(), (size_t)768 << 10) != 0) { printf("FAILED: team %d -> %d\n", team, pool.spawned()); return 1; }
