@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """cnt_bits_to_n_dev with the packed stream entered at every kind of offset inside a 4-KiB page (the output peeled to a page as
 always).  Round 4 asked "why does decode off the grid cost between 0 and 12 %" and answered "the four-tiles-per-XCD map wants
-the packed stream's 4-KiB pieces on pages".  Round 5 asks whether MOVING THE TURNS fixes it: peeling
-k = 0..3 more output pages into the head moves every turn's packed piece by k KiB (device_tier.inc decode_turn_pages), so
-for every offset this script times, INTERLEAVED over several rounds in one process on the same buffers,
+the packed stream's 4-KiB pieces on pages".  Round 5 moved the turns and found the rest; for every offset
+pair this script times, INTERLEAVED over several rounds in one process on the same buffers,
 
-    k0..k3   the shipped map with k further pages peeled (k0 = what round 4 shipped),
-    after    rule 10: the k that starts the turns in [page, page + 1 KiB) of the packed buffer,
-    nearest  rule 11: the k that starts them within 512 B of a page boundary, either side,
-    shipped  the product rule (tuning value -1),
-    plain    plain dispatch order (lab variant 42; no turns to misplace),
+    k0..k3          round 4's kernels (stream at any dword phase, shifted for a bit phase) with k further output pages peeled into
+                    the head -- every turn's packed piece moves by k KiB (device_tier.inc decode_turn_pages); k0 = round 4's launch
+    after, nearest  ... with the k that starts the turns in [page, page + 1 KiB) / within 512 B of a page boundary of the packed buffer
+    window_k0       bits_to_n_window (line-aligned 16-B loads + a funnel read of the wave's slab) for streams off their lines or
+                    dwords, no turn placement
+    window_nearest  ... with the rule
+    shipped         the product's plan (tuning values -1 / 1: window + nearest past the Infinity Cache, round 4's launch inside it)
+    plain           plain dispatch order (lab variant 42; no turns to misplace)
 
-and prints one JSON line per offset pair with the GB/s (1.25 B/nt) of each: median over rounds of the mean of `it` queued
-launches, plus the per-k packed residue r_k = (first tile's packed byte address) mod 4096.
+and prints one JSON line per pair with the GB/s (1.25 B/nt) of each -- median over rounds of the mean of `it` queued launches
+-- plus the per-k packed residue r_k = (first tile's packed byte address) mod 4096.  profiles/r05_decode_off_grid.md reads
+four boxes' sweeps and the size table (CNT_OFF_GRID_FEW_MODES=1 --quick --log2-nt 22..32).
 
     python bench/decode_off_grid.py [--log2-nt 34] [--rounds 6] [--it 4] [--quick]"""
 import argparse
