@@ -577,6 +577,22 @@ def traffic_for_line(log2_nt, n_gpus, allow_live, child_device=None):
     return traffic, source, live
 
 
+def one_device_env(parent, hip_index):
+    """Environment entries that leave a child process with exactly ONE device: the parent's HIP device `hip_index`.  Hidden at
+    the ROCr level (ROCR_VISIBLE_DEVICES), so that rocprofv3 itself -- which enumerates HSA agents, not HIP devices -- sets its
+    counters up on that agent only; HIP then sees it as device 0.  HIP_VISIBLE_DEVICES indexes into the ROCr-visible set, so a
+    list the parent was given is resolved first; entries that are not plain indices (UUIDs) fall back to filtering in HIP."""
+    hip = [x.strip() for x in parent.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip()]
+    rocr = [x.strip() for x in parent.get("ROCR_VISIBLE_DEVICES", "").split(",") if x.strip()]
+    try:
+        idx = int(hip[hip_index]) if hip else hip_index
+        if rocr:
+            return {"ROCR_VISIBLE_DEVICES": rocr[idx], "HIP_VISIBLE_DEVICES": "0"}
+        return {"ROCR_VISIBLE_DEVICES": str(idx), "HIP_VISIBLE_DEVICES": "0"}
+    except (ValueError, IndexError):
+        return {"HIP_VISIBLE_DEVICES": hip[hip_index] if hip_index < len(hip) else str(hip_index)}
+
+
 def measure_traffic_live(log2_nt, timeout_s=90, child_device=None):
     """HBM bytes per launch of the two timed kernels, measured by THIS run on THIS box: two child processes of
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC has 4 counter slots,
@@ -598,9 +614,8 @@ def measure_traffic_live(log2_nt, timeout_s=90, child_device=None):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CNT_BENCH_SHARE_GPU"):
         env.pop(k, None)  # the child is a plain one-device process, whatever launched the parent
-    if child_device is not None:  # N > 1: the child sees rank 0's device only (an entry of the parent's own visibility list)
-        vis = [x for x in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip()]
-        env["HIP_VISIBLE_DEVICES"] = vis[child_device] if child_device < len(vis) else str(child_device)
+    if child_device is not None:  # N > 1: the child -- rocprofv3's counter collection included -- sees rank 0's device only
+        env.update(one_device_env(os.environ, child_device))
     try:
         csvs = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

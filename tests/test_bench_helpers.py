@@ -184,3 +184,16 @@ def test_cpu_baseline_leg_for_the_n_gpu_lines(oracle):
     assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "Gnt/s" and c["one_thread"]["value"] > 0
     assert "reference_faithful_40k_GiBs" not in c and "N = 1 line" in c["reference_faithful_tables"]
     assert c["cores_detail"]["threads_timed"] == c["cores"] and "sample" in c
+
+
+def test_the_pmc_child_of_an_n_gpu_line_sees_one_device():
+    """the live-traffic leg of an N > 1 line runs rocprofv3 over a one-device child: rank 0's device, hidden at the ROCr level so
+    that the profiler's own agent enumeration is restricted too; visibility lists the parent was launched under are resolved"""
+    import bench_measure as bm
+
+    assert bm.one_device_env({}, 0) == {"ROCR_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0"}
+    assert bm.one_device_env({}, 5) == {"ROCR_VISIBLE_DEVICES": "5", "HIP_VISIBLE_DEVICES": "0"}
+    assert bm.one_device_env({"HIP_VISIBLE_DEVICES": "4,5,6,7"}, 2) == {"ROCR_VISIBLE_DEVICES": "6", "HIP_VISIBLE_DEVICES": "0"}
+    assert bm.one_device_env({"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1,0"}, 0) == {"ROCR_VISIBLE_DEVICES": "3", "HIP_VISIBLE_DEVICES": "0"}
+    assert bm.one_device_env({"ROCR_VISIBLE_DEVICES": "GPU-abc,GPU-def"}, 1) == {"ROCR_VISIBLE_DEVICES": "GPU-def", "HIP_VISIBLE_DEVICES": "0"}
+    assert bm.one_device_env({"HIP_VISIBLE_DEVICES": "GPU-abc,GPU-def"}, 1) == {"HIP_VISIBLE_DEVICES": "GPU-def"}  # UUIDs: filter in HIP
