@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "cute_nucleotides_amd", "csrc", "cute_nt.hip")
+SRC = os.path.join(ROOT, "hip", "cute_nt.hip")
 DIGEST = os.path.join(ROOT, "profiles", "r05_isa_digest.txt")
 DIGEST_R04 = os.path.join(ROOT, "profiles", "r04_isa_digest.txt")  # round 4's: the kernels both rounds ship must not have moved
 DIGEST_R03 = os.path.join(ROOT, "profiles", "r03_isa_digest.txt")  # ... nor since round 3

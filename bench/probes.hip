@@ -15,9 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../cute_nucleotides_amd/csrc/codec2_kernels.hpp"
-#include "../cute_nucleotides_amd/csrc/codec2_launch.hpp"
-#include "../cute_nucleotides_amd/csrc/codec5_kernels.hpp"
+#include "../hip/codec2_kernels.hpp"
+#include "../hip/codec2_launch.hpp"
+#include "../hip/codec5_kernels.hpp"
 
 using cnt::u32x4;
 constexpr int kBlock = 256;

@@ -1,6 +1,6 @@
 """cute_nucleotides_amd -- MI355X (gfx950) back-end for the cute-nucleotides codec hot path.
 
-Layout:  csrc/            HIP kernels + the C-ABI shim (-> libcute_nt_hip.so, include/cute_nt.h)
+Layout:  ../hip/          HIP kernels + the C-ABI shim (-> libcute_nt_hip.so, include/cute_nt.h; `make -C hip` or build.py)
          n_to_bits.py     mirror of the reference's src/n_to_bits.rs API (2-bit codec)
          n_to_bits2.py    mirror of src/n_to_bits2.rs (5-letter codec)
          devutil.py       device-side generator / checksum / compare for benches

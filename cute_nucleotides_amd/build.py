@@ -8,7 +8,7 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.path.join(os.path.dirname(HERE), "hip")
 LIB = os.path.join(HERE, "libcute_nt_hip.so")
 # the same translation unit with -DCNT_LAB_VARIANTS: every measured kernel variant + the process-global tuning knobs that
 # select them (cnt_set_tuning).  Bench / test infrastructure, kept out of the product package on purpose.
@@ -19,7 +19,7 @@ LAB_LIB = os.path.join(os.path.dirname(HERE), "bench", "libcute_nt_hip_lab.so")
 HOOKS_LIB = os.path.join(os.path.dirname(HERE), "tests", "libcute_nt_hip_hooks.so")
 SOURCES = ["cute_nt.hip"]
 # every file the one translation unit includes: a non-forced build() must notice an edit to any of them
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))) + [os.path.join("..", "..", "include", "cute_nt.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))) + [os.path.join("..", "include", "cute_nt.h")]
 ARCH = "gfx950"
 
 

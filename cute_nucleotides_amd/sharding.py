@@ -4,7 +4,7 @@ Word w depends only on nt [32w, 32w+32) (n_to_bits.rs:39-42), so the path shards
 independent units with no exchange step: GPU k of G gets nt [k*C, min(N,(k+1)*C)) with
 C = ceil(N/G) rounded up to `gran` (a whole number of kernel tiles, hence of words), every
 shard starts on a word boundary and only the last one has a tail.  The same arithmetic lives
-in csrc/sharded_tier.inc (shard_range, exported as cnt_shard_range); bench.py uses this copy for its one-process-
+in hip/sharded_tier.inc (shard_range, exported as cnt_shard_range); bench.py uses this copy for its one-process-
 per-GPU launch.  No collective anywhere on the data path.
 """
 

@@ -140,6 +140,67 @@ __device__ __forceinline__ uint32_t enc16(u32x4 q) {
 }
 
 // ---------------------------------------------------------------------------
+// validity while encoding (round 6): the *_checked entry points count the bytes outside the codec's alphabet in the
+// SAME pass that packs them -- the reference's BYTE_LUT silently encodes every such byte as 0 (n_to_bits.rs:8-21,42) and
+// points at a separate validity check (README.md:23); encode + cnt_validate_dev is 2.25 B/nt of HBM traffic for what one
+// pass over the ASCII does at 1.25.
+// ---------------------------------------------------------------------------
+// 0x80 in every byte of x that is NOT a letter of the alphabet: ACGTUacgtu, with ALLOW_N also Nn (the 5-letter codec's,
+// n_to_bits2.rs:8-23).  strict_filter's test: the low three bits say which upper-case letter the byte would have to be.
+template <bool ALLOW_N>
+__device__ __forceinline__ uint32_t invalid_mask(uint32_t x) {
+    const uint32_t expect = __builtin_amdgcn_perm(ALLOW_N ? 0x474E5554u : 0x47FF5554u, 0x43FF41FFu, x & 0x07070707u);
+    const uint32_t z = (x & 0xDFDFDFDFu) ^ expect;                      // zero byte <=> valid letter (case folded)
+    return (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+}
+// The tiles' fast path does not count, it only finds out whether there is anything to count: `acc` grows by the byte-wise
+// |folded - expected| of the four bytes (v_sad_u8: and, and, perm, sad = 4 VALU per dword against 8 for the exact mask +
+// v_bcnt), so acc stays 0 exactly when every byte seen is a letter.  Clean data -- the case a validated encode is run for --
+// then costs one wave-uniform branch behind the tile's stores; a wave that saw anything recounts its registers exactly.
+template <bool ALLOW_N>
+__device__ __forceinline__ uint32_t suspect(uint32_t x, uint32_t acc) {
+    const uint32_t expect = __builtin_amdgcn_perm(ALLOW_N ? 0x474E5554u : 0x47FF5554u, 0x43FF41FFu, x & 0x07070707u);
+    return __builtin_amdgcn_sad_u8(x & 0xDFDFDFDFu, expect, acc);
+}
+template <bool ALLOW_N>
+__device__ __forceinline__ uint32_t suspect16(u32x4 q, uint32_t acc) {
+    return suspect<ALLOW_N>(q.w, suspect<ALLOW_N>(q.z, suspect<ALLOW_N>(q.y, suspect<ALLOW_N>(q.x, acc))));
+}
+template <bool ALLOW_N>
+__device__ __forceinline__ uint32_t invalid16(u32x4 q) {  // exact: bytes of the vector outside the alphabet
+    return __builtin_popcount(invalid_mask<ALLOW_N>(q.x)) + __builtin_popcount(invalid_mask<ALLOW_N>(q.y)) +
+           __builtin_popcount(invalid_mask<ALLOW_N>(q.z)) + __builtin_popcount(invalid_mask<ALLOW_N>(q.w));
+}
+// the same with only bytes [lo, hi) of the vector counted (0 <= lo, hi <= 16; the window kernels' first and last rows):
+// every other byte is replaced by 'A', a letter
+template <bool ALLOW_N>
+__device__ __forceinline__ uint32_t invalid16_range(u32x4 q, int lo, int hi) {
+    uint32_t c = 0;
+    const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int a = lo - 4 * j, b = hi - 4 * j;  // bytes [a, b) of this dword are counted
+        const uint32_t from = a <= 0 ? 0xFFFFFFFFu : a >= 4 ? 0u : 0xFFFFFFFFu << (8 * a);
+        const uint32_t upto = b >= 4 ? 0xFFFFFFFFu : b <= 0 ? 0u : ~(0xFFFFFFFFu << (8 * b));
+        const uint32_t keep = from & upto;
+        c += __builtin_popcount(invalid_mask<ALLOW_N>((d[j] & keep) | (0x41414141u & ~keep)));
+    }
+    return c;
+}
+// one no-return atomic per wave that has something to add (none on clean data)
+__device__ __forceinline__ void wave_sum_to(uint64_t v, unsigned long long* dst) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0 && v) (void)__hip_atomic_fetch_add(dst, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wave_add_invalid(uint32_t bad, unsigned long long* dst) {
+    if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) wave_sum_to(bad, dst);
+}
+
+// ---------------------------------------------------------------------------
 // decode arithmetic: one packed byte -> 4 ASCII bytes (one dword)
 // ---------------------------------------------------------------------------
 // b | b<<6 | b<<12 | b<<18 puts code k at bits 8k..8k+1 (the spread the
@@ -216,6 +277,24 @@ __device__ __forceinline__ uint64_t encode_word_bytes(const uint8_t* __restrict_
     }
     return acc;
 }
+// the same, also counting the word's bytes outside ACGTUacgtu into `bad` (bytes that do not exist count as 'A', a letter)
+__device__ __forceinline__ uint64_t encode_word_bytes_checked(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t w, bool lut, uint32_t& bad) {
+    const uint64_t i0 = w << 5;
+    uint64_t acc = 0;
+    const int m = (n_len - i0) < 32 ? (int)(n_len - i0) : 32;
+    for (int k = 0; k < m; k += 4) {
+        uint32_t x = 0, pad = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k + j < m) x |= (uint32_t)n[i0 + k + j] << (8 * j);
+            else pad |= 0x41u << (8 * j);
+        }
+        bad += __builtin_popcount(invalid_mask<false>(x | pad));
+        if (lut) x = strict_filter(x);
+        acc |= (uint64_t)__builtin_amdgcn_ubfe(enc_gather(x & 0x06060606u), 19, 8) << (2 * k);
+    }
+    return acc;
+}
 
 // words [0, head_words) and [tail_first, words) of an encode, all relative to the caller's pointers
 struct EncodeEdges {
@@ -232,6 +311,16 @@ __device__ __forceinline__ void encode_edges(const EncodeEdges& e, uint64_t idx,
         const uint64_t w = i < e.head_words ? i : e.tail_first + (i - e.head_words);
         e.out[w] = encode_word_bytes(e.n, e.n_len, w, STRICT || w >= e.lut_from);
     }
+}
+template <bool STRICT>
+__device__ __forceinline__ uint32_t encode_edges_checked(const EncodeEdges& e, uint64_t idx, uint64_t stride) {  // returns this thread's count
+    const uint64_t items = e.head_words + (e.words - e.tail_first);
+    uint32_t bad = 0;
+    for (uint64_t i = idx; i < items; i += stride) {
+        const uint64_t w = i < e.head_words ? i : e.tail_first + (i - e.head_words);
+        e.out[w] = encode_word_bytes_checked(e.n, e.n_len, w, STRICT || w >= e.lut_from, bad);
+    }
+    return bad;
 }
 inline uint64_t encode_edge_items(const EncodeEdges& e) { return e.head_words + (e.words - e.tail_first); }
 
@@ -314,6 +403,19 @@ __device__ __forceinline__ void round_trip_edges(const RoundTripEdges& e, uint64
     }
 }
 
+template <bool STRICT>
+__device__ __forceinline__ uint32_t round_trip_edges_checked(const RoundTripEdges& e, uint64_t idx, uint64_t stride) {
+    uint32_t bad = 0;
+    for (uint64_t w = e.tail_first + idx; w < e.words; w += stride) {
+        const uint64_t acc = encode_word_bytes_checked(e.n, e.n_len, w, STRICT || w >= e.lut_from, bad);
+        e.packed[w] = acc;
+        const uint64_t i0 = w << 5;
+        const int m = (e.n_len - i0) < 32 ? (int)(e.n_len - i0) : 32;
+        for (int k = 0; k < m; ++k) e.back[i0 + k] = (uint8_t)(0x47544341u >> ((uint32_t)((acc >> (2 * k)) & 3u) << 3));
+    }
+    return bad;
+}
+
 // the end of every tile kernel: the launch's last e.groups workgroups (groups <= n_tiles) share the edge items
 #define CNT_ENCODE_EDGES_TAIL(BLOCK_)                                                                                   \
     if (blockIdx.x + e.groups >= n_tiles)                                                                               \
@@ -331,9 +433,10 @@ __device__ __forceinline__ void round_trip_edges(const RoundTripEdges& e, uint64
 
 // STREAM: 16-B loads (1 KiB per wave-instruction, coalesced) -> one packed dword
 // per lane per load, stored 4 B per lane (256 B per wave-instruction).
-template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
-__global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                          uint32_t n_tiles, uint32_t xs, EncodeEdges e) {
+// (`bad_out` / CHECK: the *_checked twin below counts the tile's bytes outside the alphabet behind its stores)
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT, bool CHECK>
+__device__ __forceinline__ void n_to_bits_stream_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t xs,
+                                                      const EncodeEdges& e, unsigned long long* __restrict__ bad_out) {
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_OUT = TILE_IN / 4;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
@@ -347,7 +450,31 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u)
         __builtin_amdgcn_raw_buffer_store_b32(enc16<STRICT>(v[u]), rout, (u * BLOCK + tid) * 4, 0, SAUX);
-    CNT_ENCODE_EDGES_TAIL(BLOCK)
+    if constexpr (CHECK) {
+        uint32_t sus = 0, bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) sus = suspect16<false>(v[u], sus);
+        if (__builtin_amdgcn_ballot_w64(sus != 0) != 0) {  // never on clean data
+#pragma unroll
+            for (int u = 0; u < U; ++u) bad += invalid16<false>(v[u]);
+        }
+        if (blockIdx.x + e.groups >= n_tiles)
+            bad += encode_edges_checked<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * BLOCK + tid, (uint64_t)e.groups * BLOCK);
+        wave_add_invalid(bad, bad_out);
+    } else {
+        CNT_ENCODE_EDGES_TAIL(BLOCK)
+    }
+}
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          uint32_t n_tiles, uint32_t xs, EncodeEdges e) {
+    n_to_bits_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, false>(in, out, n_tiles, xs, e, nullptr);
+}
+// CHECKED (round 6; cnt_n_to_bits_checked_dev): the same tile, and *bad += the number of its bytes outside ACGTUacgtu.
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void n_to_bits_stream_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                                  uint32_t n_tiles, uint32_t xs, EncodeEdges e, unsigned long long* __restrict__ bad) {
+    n_to_bits_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, true>(in, out, n_tiles, xs, e, bad);
 }
 
 // WINDOW: variant 0's one-wave shape with U loads per lane (U = 4: 4 KiB in, 1 KiB out -- the aligned kernel loses 0.6 % to
@@ -364,9 +491,9 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
 // caller's buffer.  (The OUTPUT side cannot be treated this way -- a store stream that is not
 // 64-B aligned costs ~30 %, profiles/r01_align_lab*.json -- so the launcher peels head words until
 // the stores are line-aligned and hands the resulting input phase here.)
-template <int U, int C, int LAUX, int SAUX, bool STRICT>
-__global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                          uint32_t n_tiles, uint32_t phase, uint32_t xs, EncodeEdges e) {
+template <int U, int C, int LAUX, int SAUX, bool STRICT, bool CHECK>
+__device__ __forceinline__ void n_to_bits_window_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles, uint32_t phase,
+                                                      uint32_t xs, const EncodeEdges& e, unsigned long long* __restrict__ bad_out) {
     constexpr uint32_t TILE_IN = kWave * U * 16, TILE_OUT = TILE_IN / 4, SLACK = 144;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN + SLACK);
@@ -388,7 +515,35 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
         const uint32_t o = __builtin_amdgcn_alignbit(residency_pad[u * kWave + lane + q + 1], residency_pad[u * kWave + lane + q], sh);
         __builtin_amdgcn_raw_buffer_store_b32(o, rout, (u * kWave + lane) * 4, 0, SAUX);
     }
-    CNT_ENCODE_EDGES_TAIL(kWave)
+    if constexpr (CHECK) {
+        // the tile's OWN letters are window bytes [phase, TILE_IN + phase).  The fast path looks at every byte the wave loaded
+        // (a neighbour's bad byte sends this wave to the exact count for nothing: harmless); the exact count takes the first
+        // row from byte `phase` on and the read-ahead row up to it, so that every byte of the call is counted by ONE tile.
+        uint32_t sus = 0, bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) sus = suspect16<false>(v[u], sus);
+        sus += lane <= q ? suspect16<false>(v[U], 0u) : 0u;  // lanes behind q hold the descriptor's zeros, not bytes
+        if (__builtin_amdgcn_ballot_w64(sus != 0) != 0) {
+            bad = invalid16_range<false>(v[0], (int)phase - 16 * (int)lane, 16) + invalid16_range<false>(v[U], 0, (int)phase - 16 * (int)lane);
+#pragma unroll
+            for (int u = 1; u < U; ++u) bad += invalid16<false>(v[u]);
+        }
+        if (blockIdx.x + e.groups >= n_tiles)
+            bad += encode_edges_checked<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * kWave + lane, (uint64_t)e.groups * kWave);
+        wave_add_invalid(bad, bad_out);
+    } else {
+        CNT_ENCODE_EDGES_TAIL(kWave)
+    }
+}
+template <int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          uint32_t n_tiles, uint32_t phase, uint32_t xs, EncodeEdges e) {
+    n_to_bits_window_body<U, C, LAUX, SAUX, STRICT, false>(in, out, n_tiles, phase, xs, e, nullptr);
+}
+template <int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(kWave) void n_to_bits_window_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles,
+                                                                  uint32_t phase, uint32_t xs, EncodeEdges e, unsigned long long* __restrict__ bad) {
+    n_to_bits_window_body<U, C, LAUX, SAUX, STRICT, true>(in, out, n_tiles, phase, xs, e, bad);
 }
 
 // FUSED round trip (BASELINE.json configs[3]): one pass that reads the ASCII once and writes BOTH the
@@ -561,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
         out[w] = encode_word_bytes(n, n_len, w, STRICT || w >= lut_from);
 }
 
-// STAGED: the host tier's small-call path (csrc/host_tier.inc).  The kernel reads the shim's own PINNED
+// STAGED: the host tier's small-call path (hip/host_tier.inc).  The kernel reads the shim's own PINNED
 // staging buffer over PCIe and writes the pinned result buffer: the staging base is 16-B aligned and the
 // host zero-pads the input to a whole word, so a thread takes its 32 nt with two 16-B loads issued
 // together -- ONE PCIe round trip per thread, where the generic kernel's byte loads chain several

@@ -16,7 +16,7 @@
 //   sharded_tier.inc    partition, NUMA-pinned worker pool, resident-shard runner
 //   (this file)         tuning knobs and every exported symbol of include/cute_nt.h
 //   packed_ops_abi.inc  the packed-domain operations' entry points
-#include "../../include/cute_nt.h"
+#include "../include/cute_nt.h"
 
 #include <hip/hip_runtime.h>
 

@@ -131,14 +131,7 @@ __global__ __launch_bounds__(kRedBlock) void hamming_tiles(const uint8_t* __rest
 // fast as the one-shot tiles -- and a call is one launch with ~10^3 atomics instead of tiles + a stream-ordered
 // scratch array (hipMallocAsync) + a second kernel + a free, which cost the API call 60-100 us on top of a 1.2 ms
 // kernel (hamming 0.82-0.86 -> 0.90-0.92 of the roofline at the entry point).  No allocation: capturable in a graph.
-__device__ __forceinline__ void wave_sum_to(uint64_t v, unsigned long long* dst) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    if ((threadIdx.x & 63) == 0 && v) (void)__hip_atomic_fetch_add(dst, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (wave_sum_to: codec2_kernels.hpp -- the checked encoders end in the same one-atomic-per-wave)
 
 constexpr int kHammingRunKiB = 8, kHammingWavesPerCU = 2;     // bench/tune_lab15.hip
 constexpr int kValidateRunKiB = 16, kValidateWavesPerCU = 4;

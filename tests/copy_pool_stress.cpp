@@ -1,4 +1,4 @@
-// Stress test of the host tier's staging-copy team (cute_nucleotides_amd/csrc/copy_pool.hpp) on the CPU box, built with
+// Stress test of the host tier's staging-copy team (hip/copy_pool.hpp) on the CPU box, built with
 // -fsanitize=thread by tests/test_copy_pool.py: random sizes and alignments, warm and fresh-page copies, copies that
 // follow each other at once (the helpers are still spinning) and after a pause (they have gone to sleep), pool restarts,
 // several calling threads with a pool each.  Every copy is compared byte for byte; guard bytes around the
@@ -21,7 +21,7 @@ static void test_stall(int k) {
     }
 }
 #define CNT_COPY_POOL_TEST_STALL(k) test_stall(k)
-#include "../cute_nucleotides_amd/csrc/copy_pool.hpp"
+#include "../hip/copy_pool.hpp"
 
 #include <cstdio>
 #include <random>

@@ -1,5 +1,5 @@
 """Exhaustive CPU checks of the integer identities the HIP kernels rely on
-(cute_nucleotides_amd/csrc/codec2_kernels.hpp, codec5_kernels.hpp).  The formulas are
+(hip/codec2_kernels.hpp, codec5_kernels.hpp).  The formulas are
 restated here in numpy uint32 arithmetic and compared with the oracle's definitions, so a
 wrong shift/mask/magic constant is caught without a GPU."""
 import numpy as np

@@ -1,4 +1,4 @@
-"""The host tier's staging-copy team (csrc/copy_pool.hpp) is lock-free where it matters -- helpers steal blocks from one
+"""The host tier's staging-copy team (hip/copy_pool.hpp) is lock-free where it matters -- helpers steal blocks from one
 generation-tagged counter and spin between the copies of a call -- so it gets its own stress test on the CPU box, under
 ThreadSanitizer when the toolchain has it: a data race or a lost block in there would corrupt a drop-in call's output
 silently, and the GPU tests exercise only a few hundred copies."""

@@ -1,4 +1,4 @@
-"""Where cnt_bits_to_n_dev lays its tiles (csrc/device_tier.inc decode_plan / decode_turn_pages, reached through the test hook
+"""Where cnt_bits_to_n_dev lays its tiles (hip/device_tier.inc decode_plan / decode_turn_pages, reached through the test hook
 cnt_test_decode_plan -- no device needed), for EVERY packed offset and output phase:
 
   * the output is peeled to its 128-B line, from 2^20 nt on to its 4-KiB page;

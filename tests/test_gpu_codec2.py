@@ -15,7 +15,7 @@ VALID = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
 SIZES = [1, 3, 4, 31, 32, 33, 63, 64, 65, 255, 256, 4095, 4096, 4097, 16383, 16384, 16385,
          32768 + 5, 65536, 100003, (1 << 20), (1 << 20) + 13, (1 << 22) + 16384 + 31]
 
-N_ENC_VARIANTS, N_DEC_VARIANTS = 28, 46  # kEncodeVariants / kDecodeVariants in csrc/codec2_launch.hpp (checked below)
+N_ENC_VARIANTS, N_DEC_VARIANTS = 28, 46  # kEncodeVariants / kDecodeVariants in hip/codec2_launch.hpp (checked below)
 
 
 @pytest.fixture(scope="module")
@@ -383,7 +383,7 @@ def test_config_64gib_round_trip_multi_launch(cn, oracle, torch_cuda, fullsize):
         assert np.array_equal(got, want), c
 
 
-# ---- any-alignment plan: head peel + funnel-shifted loads (csrc/device_tier.inc encode_dev/decode_dev) ----
+# ---- any-alignment plan: head peel + funnel-shifted loads (hip/device_tier.inc encode_dev/decode_dev) ----
 ALIGN_IN_OFFS = [0, 1, 2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 127]
 ALIGN_OUT_WORD_OFFS = [0, 1, 2, 3, 7, 8, 15]
 

@@ -1,7 +1,7 @@
 """The several-launch loops of every tiled launcher, at sizes of a few MiB.
 
 A kernel launch takes at most 2^31-1 threads, so the launchers cut very large buffers into several launches
-(csrc/codec2_launch.hpp: max_tiles_per_launch) -- with the default shapes that starts at 2^36 nucleotides for the 2-bit
+(hip/codec2_launch.hpp: max_tiles_per_launch) -- with the default shapes that starts at 2^36 nucleotides for the 2-bit
 encoder and never for most others, so the loops, and the rule that a call's edge work (head words, ragged end) rides in the
 LAST launch only, were exercised by two 64-GiB tests at best.  The tuning key "launch_tiles" lowers the limit: here every
 tier runs with 64 and 128 tiles per launch against the oracle, at aligned and misaligned pointers, and a captured graph

@@ -1,4 +1,4 @@
-"""The launch plan of the any-alignment fused round trip (csrc/device_tier.inc round_trip_plan, reached through the test
+"""The launch plan of the any-alignment fused round trip (hip/device_tier.inc round_trip_plan, reached through the test
 hook cnt_test_round_trip_plan -- no device needed), walked over EVERY combination of the three pointers' phases on the CPU
 box: 128 input byte phases x 8 packed-word phases x 128 (4096 for large buffers: sampled) output byte phases, at lengths
 around every boundary the plan has.  Checked for each: the aligned windows of all tiles lie inside the caller's buffer
