@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""A/B lab for the single-GPU HOST tier (cnt_n_to_bits / cnt_bits_to_n on host slices: PCIe-bound, never `value`), round 6:
+
+  numa      VERDICT r05 next-3: where the CALLER sits (near / far socket, by `taskset`) x CNT_HOST_NUMA (staging ring allocated from
+            the GPU's node + copy helpers pinned there) x copy-team size, reused outputs at 2^26 / 2^28 / 2^30 nt.  The input is
+            allocated and first-touched by the pinned child, i.e. it lies on the caller's node.
+  pipeline  VERDICT r05 next-5: chunk size (CNT_HOST_CHUNK_MI) x minimum pieces (CNT_HOST_PIECES) x copy-team size at 2^22 ... 2^30
+            nt, near socket, against the same-run pinned-hipMemcpy ceiling.
+
+Every cell is its own child process (the knobs are read once per process).  One JSON line per cell on stdout.
+
+    python bench/host_tier_lab.py numa     > gpurun_out/host_numa.jsonl
+    python bench/host_tier_lab.py pipeline > gpurun_out/host_pipeline.jsonl"""
+import ctypes
+import json
+import os
+import statistics
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def node_cpus():
+    """{node: [cpus]} from sysfs"""
+    out = {}
+    base = "/sys/devices/system/node"
+    for d in sorted(os.listdir(base)):
+        if d.startswith("node") and d[4:].isdigit():
+            cpus = []
+            for part in open(os.path.join(base, d, "cpulist")).read().strip().split(","):
+                if not part:
+                    continue
+                lo, _, hi = part.partition("-")
+                cpus += list(range(int(lo), int(hi or lo) + 1))
+            out[int(d[4:])] = cpus
+    return out
+
+
+def child(sizes, reps):
+    import numpy as np
+    import torch  # noqa: F401
+
+    import cute_nucleotides_amd as cn  # noqa: F401
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    rows = {}
+    for log2 in sizes:
+        m = 1 << log2
+        block = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, min(m, 1 << 20), dtype=np.uint8)]
+        n = np.tile(block, m // block.size)  # allocated and first touched here: on the caller's node
+        bits = np.empty(m // 32, dtype=np.uint64)
+        back = np.empty(m, dtype=np.uint8)
+        row = {}
+        for name, fn in (("enc", lambda: L.cnt_n_to_bits(p(n), m, p(bits), m // 32)), ("dec", lambda: L.cnt_bits_to_n(p(bits), m // 32, m, p(back)))):
+            assert fn() == 0 and fn() == 0
+            ts = []
+            k = reps if log2 >= 28 else reps * 3
+            for _ in range(k):
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e6)
+            row[name + "_us"] = round(statistics.median(ts), 1)
+            row[name + "_min_us"] = round(min(ts), 1)
+        assert np.array_equal(back, n)
+        rows["2^%d" % log2] = row
+    v = [ctypes.c_int(-9) for _ in range(4)]
+    L.cnt_host_tier_info(*[ctypes.byref(x) for x in v])
+    info = dict(zip(("device", "gpu_numa_node", "helper_cpus_pinned", "staging_node"), (x.value for x in v)))
+    cpu = ctypes.CDLL(None).sched_getcpu()
+    node = [d for d in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu) if d.startswith("node")]
+    info["caller_cpu"], info["caller_node"] = cpu, node[0] if node else None
+    print(json.dumps({"rows": rows, "info": info}))
+
+
+def pcie_ceiling():
+    import torch
+
+    h = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    h.zero_()
+    out = {}
+    for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[name + "_GiBs"] = round(1.0 / statistics.median(ts), 2)
+    return out
+
+
+def run_cell(env, cpus, sizes, reps):
+    cmd = [sys.executable, os.path.abspath(__file__), "child", ",".join(map(str, sizes)), str(reps)]
+    if cpus:
+        cmd = ["taskset", "-c", ",".join(map(str, cpus))] + cmd
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode or not line:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(line[-1])
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "child":
+        return child([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]))
+    import torch
+
+    from cute_nucleotides_amd import devutil
+
+    ident = devutil.device_identity(0)
+    nodes = node_cpus()
+    gpu_node = ident["numa_node"]
+    print(json.dumps({"device": ident, "nodes": {k: len(v) for k, v in nodes.items()}, "pcie": pcie_ceiling()}), flush=True)
+    del torch
+    near = nodes.get(gpu_node)
+    far = next((v for k, v in sorted(nodes.items()) if k != gpu_node and v), None)
+    if mode == "numa":
+        cells = []
+        for where, cpus in (("near", near), ("far", far), ("anywhere", None)):
+            if where != "anywhere" and not cpus:
+                continue
+            for numa in ("1", "0"):
+                for threads in ("4", "8"):
+                    cells.append((where, cpus, {"CNT_HOST_NUMA": numa, "CNT_HOST_COPY_THREADS": threads}))
+        for rnd in range(2):  # every cell twice, interleaved: one drifting box cannot favour a setting
+            for where, cpus, env in cells:
+                out = run_cell(env, cpus, (26, 28, 30), 7)
+                print(json.dumps(dict(out, caller=where, env=env, round=rnd)), flush=True)
+    elif mode == "pipeline":
+        for rnd in range(2):
+            for threads in ("4", "8"):
+                for chunk in ("16", "8", "4"):
+                    for pieces in ("4", "8", "16"):
+                        env = {"CNT_HOST_COPY_THREADS": threads, "CNT_HOST_CHUNK_MI": chunk, "CNT_HOST_PIECES": pieces}
+                        out = run_cell(env, near, (22, 24, 26, 27, 28, 30), 7)
+                        print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    else:
+        raise SystemExit("usage: host_tier_lab.py numa | pipeline")
+
+
+if __name__ == "__main__":
+    main()

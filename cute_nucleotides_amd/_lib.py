@@ -35,8 +35,11 @@ SIGNATURES = {
     "cnt_device_pci_bus_id": (_int, [_int, ctypes.c_char_p, _sz]),
     "cnt_device_numa_node": (_int, [_int, ctypes.POINTER(_int)]),
     "cnt_shutdown": (_int, []),
+    "cnt_host_tier_info": (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "cnt_n_to_bits": (_int, [_vp, _sz, _vp, _sz]),
     "cnt_n_to_bits_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
+    "cnt_n_to_bits_checked": (_int, [_vp, _sz, _vp, _sz, _uint, ctypes.POINTER(_u64)]),
+    "cnt_n_to_bits2_checked": (_int, [_vp, _sz, _vp, _sz, _uint, ctypes.POINTER(_u64)]),
     "cnt_bits_to_n": (_int, [_vp, _sz, _sz, _vp]),
     "cnt_n_to_bits2": (_int, [_vp, _sz, _vp, _sz]),
     "cnt_n_to_bits2_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
@@ -55,6 +58,8 @@ SIGNATURES = {
     "cnt_bits_to_n2_sharded_dev": (_int, [_vp, _vp, _vp, _vp, _int, _uint, _vp]),
     "cnt_sharded_dev_open": (_int, [_int, _uint, ctypes.POINTER(_vp)]),
     "cnt_sharded_dev_open_on_streams": (_int, [_int, _vp, _uint, ctypes.POINTER(_vp)]),
+    "cnt_sharded_dev_open_on_devices": (_int, [_int, ctypes.POINTER(_int), _uint, ctypes.POINTER(_vp)]),
+    "cnt_sharded_dev_device": (_int, [_vp, _int, ctypes.POINTER(_int)]),
     "cnt_sharded_dev_wait_event": (_int, [_vp, _int, _vp]),
     "cnt_sharded_dev_record_event": (_int, [_vp, _int, _vp]),
     "cnt_sharded_dev_close": (_int, [_vp]),
@@ -64,6 +69,9 @@ SIGNATURES = {
     "cnt_round_trip_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _uint]),
     "cnt_n_to_bits2_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
     "cnt_bits_to_n2_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint]),
+    "cnt_n_to_bits_checked_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint, _vp]),
+    "cnt_n_to_bits2_checked_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _uint, _vp]),
+    "cnt_round_trip_checked_sharded_dev_enqueue": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _uint, _vp]),
     "cnt_sharded_dev_wait": (_int, [_vp, _vp]),
     "cnt_sharded_dev_op_ms": (_int, [_vp, _sz, _vp]),
     "cnt_n_to_bits_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
@@ -71,6 +79,9 @@ SIGNATURES = {
     "cnt_n_to_bits2_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp]),
     "cnt_round_trip_dev": (_int, [_vp, _sz, _vp, _sz, _vp, _uint, _vp]),
     "cnt_bits_to_n2_dev": (_int, [_vp, _sz, _sz, _vp, _uint, _vp]),
+    "cnt_n_to_bits_checked_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp, _vp]),
+    "cnt_n_to_bits2_checked_dev": (_int, [_vp, _sz, _vp, _sz, _uint, _vp, _vp]),
+    "cnt_round_trip_checked_dev": (_int, [_vp, _sz, _vp, _sz, _vp, _uint, _vp, _vp]),
     "cnt_dev_alloc": (_int, [ctypes.POINTER(_vp), _sz]),
     "cnt_dev_free": (_int, [_vp]),
     "cnt_dev_upload": (_int, [_vp, _vp, _sz]),
@@ -92,6 +103,7 @@ SIGNATURES = {
     "cnt_get_tuning": (_int, [ctypes.c_char_p, ctypes.POINTER(_int)]),
     "cnt_tuning_name": (ctypes.c_char_p, [ctypes.c_char_p, _int]),
     "cnt_chip_info": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "cnt_chip_cache_nt": (_int, [_int, ctypes.POINTER(_u64)]),
     "cnt_check_device_range": (_int, [ctypes.c_void_p, ctypes.c_size_t, _int]),
 }
 # exported by the hooks build and the lab build ONLY (include/cute_nt.h, under #ifdef CNT_TEST_HOOKS)
@@ -99,7 +111,7 @@ TEST_HOOK_SIGNATURES = {
     "cnt_test_alias_devices": (_int, [_int]),
     "cnt_test_advise_output": (_int, [_vp, _sz]),
     "cnt_test_round_trip_plan": (_int, [_u64, _u64, _u64, _u64, _uint, ctypes.POINTER(_u64)]),
-    "cnt_test_decode_plan": (_int, [_u64, _u64, _u64, ctypes.POINTER(_u64)]),
+    "cnt_test_decode_plan": (_int, [_u64, _u64, _u64, _u64, ctypes.POINTER(_u64)]),
 }
 CNT_QUEUE_MAX_TIMED_OPS = 4096
 

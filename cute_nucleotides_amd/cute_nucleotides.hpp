@@ -89,6 +89,15 @@ inline Vec<uint64_t> n_to_bits_hip(const uint8_t* n, size_t len, bool strict_lut
 template <class A>
 inline Vec<uint64_t> n_to_bits_hip(const std::vector<uint8_t, A>& n) { return n_to_bits_hip(n.data(), n.size()); }
 
+/// The same encode VALIDATED in the same pass over the data: `invalid` receives the number of bytes outside ACGTUacgtu -- what
+/// the reference's BYTE_LUT turns into code 0 without a word (n_to_bits.rs:8-21,42; README.md:23 points at a separate check).
+/// The words are n_to_bits_hip's whatever the count says.
+inline Vec<uint64_t> n_to_bits_hip_checked(const uint8_t* n, size_t len, uint64_t& invalid, bool strict_lut = false, bool tail_lut = false) {
+    Vec<uint64_t> out(cnt_words_for(len));
+    detail::check(cnt_n_to_bits_checked(n, len, out.data(), out.size(), (strict_lut ? CNT_STRICT_LUT : 0u) | (tail_lut ? CNT_TAIL_LUT : 0u), &invalid));
+    return out;
+}
+
 /// Decode `len` nucleotides (n_to_bits.rs:51-69 and the three SIMD siblings).
 inline Vec<uint8_t> bits_to_n_hip(const uint64_t* bits, size_t words, size_t len) {
     if (len > (words << 5)) detail::check(CNT_ELEN);
@@ -140,6 +149,13 @@ inline Vec<uint64_t> n_to_bits2_hip(const uint8_t* n, size_t len) {
 }
 template <class A>
 inline Vec<uint64_t> n_to_bits2_hip(const std::vector<uint8_t, A>& n) { return n_to_bits2_hip(n.data(), n.size()); }
+
+/// ... validated in the same pass: `invalid` = bytes outside ACGTUNacgtun (n_to_bits2.rs:8-23)
+inline Vec<uint64_t> n_to_bits2_hip_checked(const uint8_t* n, size_t len, uint64_t& invalid) {
+    Vec<uint64_t> out(cnt_words2_for(len));
+    detail::check(cnt_n_to_bits2_checked(n, len, out.data(), out.size(), 0u, &invalid));
+    return out;
+}
 
 /// n_to_bits2.rs:78-107, :196-268.
 inline Vec<uint8_t> bits_to_n2_hip(const uint64_t* bits, size_t words, size_t len) {
@@ -210,6 +226,12 @@ inline void n_to_bits_hip_dev(const DeviceBuffer& n, size_t n_len, DeviceBuffer&
     if (n_len > n.size_bytes()) throw std::out_of_range("n_to_bits_hip_dev: n_len");
     detail::check(cnt_n_to_bits_dev(n.data(), n_len, out.data(), out.size_bytes() / 8, strict_lut ? CNT_STRICT_LUT : 0u, nullptr));
 }
+/// Encode + validity count in ONE pass over the resident ASCII (cnt_n_to_bits_checked_dev): the launch ADDS the number of
+/// bytes outside ACGTUacgtu to the u64 at `invalid` (device memory the caller zeroed, e.g. an 8-byte DeviceBuffer).
+inline void n_to_bits_hip_checked_dev(const DeviceBuffer& n, size_t n_len, DeviceBuffer& out, DeviceBuffer& invalid, bool strict_lut = false) {
+    if (n_len > n.size_bytes() || invalid.size_bytes() < 8) throw std::out_of_range("n_to_bits_hip_checked_dev: sizes");
+    detail::check(cnt_n_to_bits_checked_dev(n.data(), n_len, out.data(), out.size_bytes() / 8, strict_lut ? CNT_STRICT_LUT : 0u, invalid.data(), nullptr));
+}
 /// Enqueue the decode of `len` nucleotides from `words` resident words into `out` (>= len bytes).
 inline void bits_to_n_hip_dev(const DeviceBuffer& bits, size_t words, size_t len, DeviceBuffer& out) {
     if (len > (words << 5)) detail::check(CNT_ELEN);
@@ -236,7 +258,39 @@ class ShardedDevQueue {
         detail::check(cnt_sharded_dev_open_on_streams((int)streams.size(), streams.data(), timed ? CNT_QUEUE_TIMED : 0u, &handle_));
         detail::check(cnt_sharded_dev_shards(handle_, &ndev_));
     }
-    ~ShardedDevQueue() { (void)cnt_sharded_dev_close(handle_); }
+    /// library-owned streams on an explicit device list: shard k runs on devices[k] (any subset, order or repetition)
+    static ShardedDevQueue on_devices(const std::vector<int>& devices, bool timed = false) {
+        void* h = nullptr;
+        detail::check(cnt_sharded_dev_open_on_devices((int)devices.size(), devices.data(), timed ? CNT_QUEUE_TIMED : 0u, &h));
+        return ShardedDevQueue(h);
+    }
+    ShardedDevQueue(ShardedDevQueue&& o) noexcept : handle_(o.handle_), ndev_(o.ndev_) { o.handle_ = nullptr; }
+    ~ShardedDevQueue() {
+        if (handle_) (void)cnt_sharded_dev_close(handle_);
+    }
+    /// the device the queue runs shard k on -- for adopted streams what the STREAM says (hipStreamGetDevice), not k
+    int device(int k) const {
+        int d = -1;
+        detail::check(cnt_sharded_dev_device(handle_, k, &d));
+        return d;
+    }
+    /// the validated encode on every shard: shard k's op adds its count of bytes outside ACGTUacgtu to the u64 in invalid[k]
+    /// (8 bytes on shard k's device, zeroed by the caller)
+    void enqueue_n_to_bits_checked(const std::vector<const DeviceBuffer*>& n, const std::vector<size_t>& n_len, const std::vector<DeviceBuffer*>& out,
+                                   const std::vector<DeviceBuffer*>& invalid, bool strict_lut = false) {
+        if ((int)n.size() != ndev_ || (int)n_len.size() != ndev_ || (int)out.size() != ndev_ || (int)invalid.size() != ndev_) throw std::invalid_argument("one entry per shard");
+        std::vector<const void*> in(n.size());
+        std::vector<void*> o(n.size()), c(n.size());
+        std::vector<size_t> cap(n.size());
+        for (size_t k = 0; k < n.size(); ++k) {
+            if (n_len[k] > n[k]->size_bytes() || invalid[k]->size_bytes() < 8) throw std::out_of_range("enqueue_n_to_bits_checked: sizes");
+            in[k] = n[k]->data();
+            o[k] = out[k]->data();
+            c[k] = invalid[k]->data();
+            cap[k] = out[k]->size_bytes() / 8;
+        }
+        detail::check(cnt_n_to_bits_checked_sharded_dev_enqueue(handle_, in.data(), n_len.data(), o.data(), cap.data(), strict_lut ? CNT_STRICT_LUT : 0u, c.data()));
+    }
     /// shard k's stream waits ON THE DEVICE for `event` (a hipEvent_t recorded behind the producer of shard k's buffer)
     void wait_event(int k, void* event) { detail::check(cnt_sharded_dev_wait_event(handle_, k, event)); }
     /// records the caller's hipEvent_t (of shard k's device) behind everything queued for shard k so far
@@ -298,6 +352,7 @@ class ShardedDevQueue {
     }
 
    private:
+    explicit ShardedDevQueue(void* adopted_handle) : handle_(adopted_handle) { detail::check(cnt_sharded_dev_shards(handle_, &ndev_)); }
     void* handle_ = nullptr;
     int ndev_ = 0;
 };

@@ -63,6 +63,17 @@ def n_to_bits_hip(n, strict_lut=False, tail_lut=False):
     return out
 
 
+def n_to_bits_hip_checked(n, strict_lut=False, tail_lut=False):
+    """n_to_bits_hip and, from the same pass over the data, the number of bytes outside ACGTUacgtu -- what the reference's
+    BYTE_LUT turns into code 0 without a word (n_to_bits.rs:8-21,42; README.md:23 points at a separate check).  Returns
+    (words, invalid): the words are n_to_bits_hip's whatever `invalid` says."""
+    n = _u8(n)
+    out = np.empty(lib().cnt_words_for(n.size), dtype=np.uint64)
+    bad = ctypes.c_uint64(0)
+    check(lib().cnt_n_to_bits_checked(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut), ctypes.byref(bad)))
+    return out, bad.value
+
+
 def bits_to_n_hip(bits, length):
     """Decode `length` nucleotides from packed words (n_to_bits.rs:51-69).
 
@@ -184,6 +195,45 @@ def n_to_bits_dev(n, out=None, strict_lut=False, tail_lut=False):
     _enqueue(n, lib().cnt_n_to_bits_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
              out.numel(), encode_flags(strict_lut, tail_lut))
     return out[:words]
+
+
+def _counter(torch, acc, like):
+    """the device u64 a counting entry point ADDS to: a fresh zeroed scalar, or the caller's (which the CALLER zeroes, so that
+    several calls can accumulate into one counter without a kernel in between)"""
+    if acc is None:
+        return torch.zeros(1, dtype=torch.int64, device=like.device)
+    if acc.dtype != torch.int64 or not acc.is_cuda or acc.device != like.device or acc.numel() < 1 or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous int64 CUDA tensor on the input's device")
+    return acc
+
+
+def n_to_bits_checked_dev(n, out=None, acc=None, strict_lut=False, tail_lut=False):
+    """Device-resident encode + validity count in ONE pass (cnt_n_to_bits_checked_dev): returns (words, acc) where acc is a
+    device int64 scalar the call ADDED the number of bytes outside ACGTUacgtu to (a fresh zeroed one unless the caller passes
+    its own).  1.25 B/nt of HBM traffic, where validate_dev + n_to_bits_dev is 2.25.  acc.item() synchronises."""
+    torch = _dev_guard(n)
+    if n.dtype != torch.uint8:
+        raise TypeError("nucleotides must be a uint8 tensor")
+    words = lib().cnt_words_for(n.numel())
+    out = _out_words(torch, out, words, n)
+    acc = _counter(torch, acc, n)
+    _enqueue(n, lib().cnt_n_to_bits_checked_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
+             out.numel(), encode_flags(strict_lut, tail_lut), ctypes.c_void_p(acc.data_ptr()))
+    return out[:words], acc
+
+
+def round_trip_checked_dev(n, out_bits=None, out_n=None, acc=None, strict_lut=False, tail_lut=False):
+    """round_trip_dev + the validity count of n_to_bits_checked_dev, still one pass: (words, canonical ASCII, acc)"""
+    torch = _dev_guard(n)
+    if n.dtype != torch.uint8:
+        raise TypeError("nucleotides must be a uint8 tensor")
+    words = lib().cnt_words_for(n.numel())
+    out_bits = _out_words(torch, out_bits, words, n)
+    out_n = _out_bytes(torch, out_n, n.numel(), n)
+    acc = _counter(torch, acc, n)
+    _enqueue(n, lib().cnt_round_trip_checked_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out_bits.data_ptr()),
+             out_bits.numel(), ctypes.c_void_p(out_n.data_ptr()), encode_flags(strict_lut, tail_lut), ctypes.c_void_p(acc.data_ptr()))
+    return out_bits[:words], out_n[: n.numel()], acc
 
 
 def round_trip_dev(n, out_bits=None, out_n=None, strict_lut=False, tail_lut=False):

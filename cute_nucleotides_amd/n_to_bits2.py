@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, lib
-from .n_to_bits import _dev_guard, _enqueue, _out_bytes, _out_words, _own_out, _p, _u8, _u64, encode_flags
+from .n_to_bits import _counter, _dev_guard, _enqueue, _out_bytes, _out_words, _own_out, _p, _u8, _u64, encode_flags
 
 
 def n_to_bits2_hip(n, strict_lut=False, tail_lut=False):
@@ -21,6 +21,16 @@ def n_to_bits2_hip(n, strict_lut=False, tail_lut=False):
     out = np.empty(lib().cnt_words2_for(n.size), dtype=np.uint64)
     check(lib().cnt_n_to_bits2_ex(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut)))
     return out
+
+
+def n_to_bits2_hip_checked(n, strict_lut=False, tail_lut=False):
+    """n_to_bits2_hip and, from the same pass, the number of bytes outside ACGTUNacgtun (BYTE_LUT's alphabet, n_to_bits2.rs:8-23):
+    (words, invalid)"""
+    n = _u8(n)
+    out = np.empty(lib().cnt_words2_for(n.size), dtype=np.uint64)
+    bad = ctypes.c_uint64(0)
+    check(lib().cnt_n_to_bits2_checked(_p(n), n.size, _p(out), out.size, encode_flags(strict_lut, tail_lut), ctypes.byref(bad)))
+    return out, bad.value
 
 
 def bits_to_n2_hip(bits, length):
@@ -81,6 +91,19 @@ def n_to_bits2_dev(n, out=None, strict_lut=False, tail_lut=False):
     _enqueue(n, lib().cnt_n_to_bits2_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
              out.numel(), encode_flags(strict_lut, tail_lut))
     return out[:words]
+
+
+def n_to_bits2_checked_dev(n, out=None, acc=None, strict_lut=False, tail_lut=False):
+    """n_to_bits2_dev + the number of bytes outside ACGTUNacgtun added to the device scalar `acc`, one pass: (words, acc)"""
+    torch = _dev_guard(n)
+    if n.dtype != torch.uint8:
+        raise TypeError("nucleotides must be a uint8 tensor")
+    words = lib().cnt_words2_for(n.numel())
+    out = _out_words(torch, out, words, n)
+    acc = _counter(torch, acc, n)
+    _enqueue(n, lib().cnt_n_to_bits2_checked_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
+             out.numel(), encode_flags(strict_lut, tail_lut), ctypes.c_void_p(acc.data_ptr()))
+    return out[:words], acc
 
 
 def bits_to_n2_dev(bits, length, out=None):

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from ._lib import check, lib
-from .n_to_bits import _dev_guard, _enqueue, _out_words, _p, _u8, _u64
+from .n_to_bits import _counter, _dev_guard, _enqueue, _out_words, _p, _u8, _u64
 
 CNT_ALLOW_N = 0x2
 
@@ -53,16 +53,6 @@ def validate_hip(n, allow_n=False):
 
 
 # ---- device tier --------------------------------------------------------------------------
-def _counter(torch, acc, like):
-    """the device u64 a reduction adds into: a fresh zeroed scalar, or the caller's (which the CALLER zeroes --
-    the C entry points add to it, so several calls can accumulate into one counter without a kernel in between)"""
-    if acc is None:
-        return torch.zeros(1, dtype=torch.int64, device=like.device)
-    if acc.dtype != torch.int64 or not acc.is_cuda or acc.device != like.device or acc.numel() < 1 or not acc.is_contiguous():
-        raise ValueError("acc must be a contiguous int64 CUDA tensor on the input's device")
-    return acc
-
-
 def hamming_dev(a, b, length, acc=None):
     torch = _dev_guard(a)
     _dev_guard(b)

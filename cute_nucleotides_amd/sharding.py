@@ -69,10 +69,11 @@ def alias_devices(on):
     return bool(_lib.lib().cnt_test_alias_devices(1 if on else 0))
 
 
-def _check_placement(shards, outs, extra=None):
-    """The C side runs shard k on device k % visible unconditionally (under alias_devices; device k otherwise): a
-    tensor living anywhere else would reach the kernel as a foreign-device pointer and fault the process.  Lists of
-    unequal length would make the library read past the ctypes arrays.  Both are ValueErrors here."""
+def _check_placement(shards, outs, extra=None, devices=None):
+    """The C side runs shard k on device k % visible unconditionally (under alias_devices; device k otherwise) -- or, for a
+    queue opened on streams or on a device list, on the device the QUEUE reports for shard k (`devices`,
+    cnt_sharded_dev_device): a tensor living anywhere else would reach the kernel as a foreign-device pointer and fault the
+    process.  Lists of unequal length would make the library read past the ctypes arrays.  Both are ValueErrors here."""
     import ctypes
 
     import torch
@@ -82,6 +83,12 @@ def _check_placement(shards, outs, extra=None):
     if len(outs) != len(shards) or (extra is not None and len(extra) != len(shards)):
         raise ValueError("shards, outs and lengths must have one entry per shard (%d, %d%s)"
                          % (len(shards), len(outs), "" if extra is None else ", %d" % len(extra)))
+    if devices is not None:
+        for k, (t, o) in enumerate(zip(shards, outs)):
+            for x in (t, o):
+                if x.device.index != devices[k]:
+                    raise ValueError("shard %d lives on %s but this queue runs shard %d on cuda:%d" % (k, x.device, k, devices[k]))
+        return
     count = ctypes.c_int(0)
     check(lib().cnt_device_count(ctypes.byref(count)))
     if count.value <= 0:
@@ -200,9 +207,12 @@ class DevQueue:
         consumer_stream_k.wait_event(done)                      # a torch stream reads the outputs behind them
 
     or hand the queue the caller's streams (`DevQueue(streams=[torch.cuda.Stream(k) ...])`, cnt_sharded_dev_open_on_streams):
-    shard k's ops are then enqueued on streams[k], in order with everything else the caller puts there."""
+    shard k's ops are then enqueued on streams[k], in order with everything else the caller puts there -- the queue asks every
+    stream which device it belongs to, so the streams may come in any order.  `DevQueue(devices=[2, 3, 2])` puts shard k on
+    devices[k] (cnt_sharded_dev_open_on_devices: any subset, order or repetition of the visible devices).  `q.devices[k]` is
+    where the queue runs shard k (cnt_sharded_dev_device): its tensors must live there."""
 
-    def __init__(self, ndev=0, timed=False, streams=None):
+    def __init__(self, ndev=0, timed=False, streams=None, devices=None):
         import ctypes
 
         from . import _lib
@@ -212,6 +222,9 @@ class DevQueue:
         self._h = ctypes.c_void_p()
         flags = _lib.CNT_QUEUE_TIMED if timed else 0
         self._streams = None
+        explicit = streams is not None or devices is not None
+        if streams is not None and devices is not None:
+            raise ValueError("streams already say where every shard runs: pass streams or devices, not both")
         if streams is not None:
             if ndev not in (0, len(streams)):
                 raise ValueError("ndev = %d but %d streams" % (ndev, len(streams)))
@@ -220,11 +233,21 @@ class DevQueue:
                 raise ValueError("a queue never adopts the legacy default stream (handle 0)")
             self._streams = list(streams)  # the caller's streams outlive the queue
             check(self._L.cnt_sharded_dev_open_on_streams(len(handles), _ptr_array(handles), flags, ctypes.byref(self._h)))
+        elif devices is not None:
+            if ndev not in (0, len(devices)):
+                raise ValueError("ndev = %d but %d devices" % (ndev, len(devices)))
+            check(self._L.cnt_sharded_dev_open_on_devices(len(devices), (ctypes.c_int * len(devices))(*[int(d) for d in devices]), flags, ctypes.byref(self._h)))
         else:
             check(self._L.cnt_sharded_dev_open(ndev, flags, ctypes.byref(self._h)))
         n = ctypes.c_int(0)
         check(self._L.cnt_sharded_dev_shards(self._h, ctypes.byref(n)))
         self.ndev, self.timed, self._keep, self.ops = n.value, timed, [], 0
+        self.devices = []
+        for k in range(self.ndev):
+            d = ctypes.c_int(-1)
+            check(self._L.cnt_sharded_dev_device(self._h, k, ctypes.byref(d)))
+            self.devices.append(d.value)
+        self._placement = self.devices if explicit else None  # default queues keep the k % visible rule's error text
 
     @property
     def handle(self):
@@ -256,8 +279,10 @@ class DevQueue:
         if len(shards) != self.ndev:
             raise ValueError("this queue drives %d shards, got %d" % (self.ndev, len(shards)))
 
-    def n_to_bits(self, shards, outs, five_letter=False, strict_lut=False, tail_lut=False):
-        """queue one encode of every shard (uint8 CUDA tensor on device k) into outs[k] (int64, >= words); returns at once"""
+    def n_to_bits(self, shards, outs, five_letter=False, strict_lut=False, tail_lut=False, invalid=None):
+        """queue one encode of every shard (uint8 CUDA tensor on device k) into outs[k] (int64, >= words); returns at once.
+        `invalid` (a list of device int64 scalars the caller zeroed, one per shard): the VALIDATED encode -- shard k's op also
+        adds the number of its bytes outside the codec's alphabet to invalid[k], in the same pass"""
         import torch
 
         from ._lib import check
@@ -270,12 +295,28 @@ class DevQueue:
                 raise ValueError("shards must be contiguous uint8 CUDA tensors")
             if o.dtype != torch.int64 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < words_for(t.numel()):
                 raise ValueError("outs[k] must be a contiguous int64 CUDA tensor on shard k's device with >= words elements")
-        _check_placement(shards, outs)
-        fn = self._L.cnt_n_to_bits2_sharded_dev_enqueue if five_letter else self._L.cnt_n_to_bits_sharded_dev_enqueue
-        self._keep.append((shards, outs))
-        check(fn(self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
-                 _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), _size_array([o.numel() for o in outs]), encode_flags(strict_lut, tail_lut)))
+        _check_placement(shards, outs, devices=self._placement)
+        args = [self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+                _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), _size_array([o.numel() for o in outs]), encode_flags(strict_lut, tail_lut)]
+        if invalid is None:
+            fn = self._L.cnt_n_to_bits2_sharded_dev_enqueue if five_letter else self._L.cnt_n_to_bits_sharded_dev_enqueue
+        else:  # the validated form: shard k's op adds its count of bytes outside the alphabet to invalid[k] (the caller zeroes it)
+            self._counters(shards, invalid)
+            fn = self._L.cnt_n_to_bits2_checked_sharded_dev_enqueue if five_letter else self._L.cnt_n_to_bits_checked_sharded_dev_enqueue
+            args.append(_ptr_array([c.data_ptr() for c in invalid]))
+        self._keep.append((shards, outs, invalid))
+        check(fn(*args))
         self.ops += 1
+
+    @staticmethod
+    def _counters(shards, invalid):
+        import torch
+
+        if len(invalid) != len(shards):
+            raise ValueError("invalid must have one counter per shard")
+        for t, c in zip(shards, invalid):
+            if c.dtype != torch.int64 or not c.is_cuda or c.device != t.device or c.numel() < 1 or not c.is_contiguous():
+                raise ValueError("invalid[k] must be a contiguous int64 CUDA tensor on shard k's device")
 
     def bits_to_n(self, shards, lengths, outs, five_letter=False):
         """queue one decode of every shard (int64 words on device k, lengths[k] nucleotides) into outs[k] (uint8, >= length)"""
@@ -295,14 +336,14 @@ class DevQueue:
                 check(_lib.CNT_ELEN)
             if o.dtype != torch.uint8 or not o.is_cuda or not o.is_contiguous() or o.device != t.device or o.numel() < n:
                 raise ValueError("outs[k] must be a contiguous uint8 CUDA tensor on shard k's device with >= length elements")
-        _check_placement(shards, outs, lengths)
+        _check_placement(shards, outs, lengths, devices=self._placement)
         fn = self._L.cnt_bits_to_n2_sharded_dev_enqueue if five_letter else self._L.cnt_bits_to_n_sharded_dev_enqueue
         self._keep.append((shards, outs))
         check(fn(self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
                  _size_array(list(lengths)), _ptr_array([o.data_ptr() if o.numel() else 0 for o in outs]), 0))
         self.ops += 1
 
-    def round_trip(self, shards, out_bits, out_n, strict_lut=False, tail_lut=False):
+    def round_trip(self, shards, out_bits, out_n, strict_lut=False, tail_lut=False, invalid=None):
         """queue one FUSED encode + decode of every shard (cnt_round_trip_sharded_dev_enqueue): out_bits[k] = n_to_bits(shards[k]),
         out_n[k] = its decoded canonical spelling"""
         import torch
@@ -320,12 +361,17 @@ class DevQueue:
                 raise ValueError("out_bits[k] must be a contiguous int64 CUDA tensor on shard k's device with >= words elements")
             if b.dtype != torch.uint8 or not b.is_cuda or not b.is_contiguous() or b.device != t.device or b.numel() < t.numel():
                 raise ValueError("out_n[k] must be a contiguous uint8 CUDA tensor on shard k's device with >= n_len elements")
-        _check_placement(shards, out_bits)
-        self._keep.append((shards, out_bits, out_n))
-        check(self._L.cnt_round_trip_sharded_dev_enqueue(
-            self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
-            _ptr_array([o.data_ptr() if o.numel() else 0 for o in out_bits]), _size_array([o.numel() for o in out_bits]),
-            _ptr_array([b.data_ptr() if b.numel() else 0 for b in out_n]), encode_flags(strict_lut, tail_lut)))
+        _check_placement(shards, out_bits, devices=self._placement)
+        args = [self._h, _ptr_array([t.data_ptr() if t.numel() else 0 for t in shards]), _size_array([t.numel() for t in shards]),
+                _ptr_array([o.data_ptr() if o.numel() else 0 for o in out_bits]), _size_array([o.numel() for o in out_bits]),
+                _ptr_array([b.data_ptr() if b.numel() else 0 for b in out_n]), encode_flags(strict_lut, tail_lut)]
+        fn = self._L.cnt_round_trip_sharded_dev_enqueue
+        if invalid is not None:
+            self._counters(shards, invalid)
+            fn = self._L.cnt_round_trip_checked_sharded_dev_enqueue
+            args.append(_ptr_array([c.data_ptr() for c in invalid]))
+        self._keep.append((shards, out_bits, out_n, invalid))
+        check(fn(*args))
         self.ops += 1
 
     @staticmethod

@@ -551,9 +551,9 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window_checked(const uint8_t*
 // built is decoded from registers, so the packed form is never read back: 1 + 0.25 + 1 = 2.25 B/nt
 // instead of the 2.5 B/nt of encode followed by decode.  Launched as <64, 4, 1>: one wave, four loads
 // per lane, 4 KiB of ASCII per workgroup, plain dispatch order (codec2_launch.hpp, bench/tune_lab11.hip).
-template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
-__global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed,
-                                                           uint8_t* __restrict__ back, uint32_t n_tiles, uint32_t xs, RoundTripEdges e) {
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT, bool CHECK>
+__device__ __forceinline__ void round_trip_stream_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back,
+                                                       uint32_t n_tiles, uint32_t xs, const RoundTripEdges& e, unsigned long long* __restrict__ bad_out) {
     constexpr uint32_t TILE_IN = BLOCK * U * 16, TILE_PK = TILE_IN / 4;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE_IN, TILE_IN);
@@ -571,8 +571,31 @@ __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __rest
         __builtin_amdgcn_raw_buffer_store_b32(code, rpk, (u * BLOCK + tid) * 4, 0, SAUX);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(code)), rbk, (u * BLOCK + tid) * 16, 0, SAUX);
     }
-    if (blockIdx.x + e.groups >= n_tiles)
-        round_trip_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * BLOCK + tid, (uint64_t)e.groups * BLOCK);
+    if constexpr (CHECK) {
+        uint32_t sus = 0, bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) sus = suspect16<false>(v[u], sus);
+        if (__builtin_amdgcn_ballot_w64(sus != 0) != 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) bad += invalid16<false>(v[u]);
+        }
+        if (blockIdx.x + e.groups >= n_tiles)
+            bad += round_trip_edges_checked<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * BLOCK + tid, (uint64_t)e.groups * BLOCK);
+        wave_add_invalid(bad, bad_out);
+    } else {
+        if (blockIdx.x + e.groups >= n_tiles)
+            round_trip_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * BLOCK + tid, (uint64_t)e.groups * BLOCK);
+    }
+}
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed,
+                                                           uint8_t* __restrict__ back, uint32_t n_tiles, uint32_t xs, RoundTripEdges e) {
+    round_trip_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, false>(in, packed, back, n_tiles, xs, e, nullptr);
+}
+template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(BLOCK) void round_trip_stream_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back,
+                                                                   uint32_t n_tiles, uint32_t xs, RoundTripEdges e, unsigned long long* __restrict__ bad) {
+    round_trip_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, true>(in, packed, back, n_tiles, xs, e, bad);
 }
 
 // FUSED round trip at ANY alignment of its three pointers, still one pass and one launch (round 4).  The tile is laid
@@ -606,11 +629,14 @@ struct RoundTripEdgesAny {
     uint64_t lut_from;  // words >= lut_from take BYTE_LUT semantics (kNoLutWord: none)
     uint32_t groups;
 };
-template <bool STRICT>
-__device__ __forceinline__ void round_trip_edges_any(const RoundTripEdgesAny& e, uint64_t idx, uint64_t stride) {
+// CHECK: returns the number of bytes outside ACGTUacgtu among the letters the TILES do not own (i < t0 or i >= t1: exactly
+// the letters this body spells out), so that tiles + edge items count every byte of the call once
+template <bool STRICT, bool CHECK = false>
+__device__ __forceinline__ uint32_t round_trip_edges_any(const RoundTripEdgesAny& e, uint64_t idx, uint64_t stride) {
     // dwords [0, h) and [f, dwords) hold a letter or a packed dword that the tiles do not write
     const uint64_t h = max(e.p0, (e.t0 + 15) >> 4), f = min(e.p1, e.t1 >> 4);
     const uint64_t items = h + (e.dwords - f);
+    uint32_t bad = 0;
     for (uint64_t k = idx; k < items; k += stride) {
         const uint64_t d = k < h ? k : f + (k - h);
         const uint64_t i0 = d << 4;
@@ -622,6 +648,13 @@ __device__ __forceinline__ void round_trip_edges_any(const RoundTripEdgesAny& e,
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (q + j < m) x |= (uint32_t)e.n[i0 + q + j] << (8 * j);
+            if constexpr (CHECK) {
+                uint32_t keep = 0;  // 0xFF per byte that exists and lies outside the tiles' letters
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q + j < m && (i0 + q + j < e.t0 || i0 + q + j >= e.t1)) keep |= 0xFFu << (8 * j);
+                bad += __builtin_popcount(invalid_mask<false>((x & keep) | (0x41414141u & ~keep)));
+            }
             if (lut) x = strict_filter(x);
             code |= __builtin_amdgcn_ubfe(enc_gather(x & 0x06060606u), 19, 8) << (2 * q);
         }
@@ -631,14 +664,15 @@ __device__ __forceinline__ void round_trip_edges_any(const RoundTripEdgesAny& e,
             if (i < e.t0 || i >= e.t1) e.back[i] = (uint8_t)(0x47544341u >> (((code >> (2 * q)) & 3u) << 3));  // "ACTG"[code]
         }
     }
+    return bad;
 }
 constexpr uint32_t kRoundTripAnyTile = 64 * 4 * 16;
 constexpr uint32_t kRoundTripAnySlackVecs = 25;  // 16-B vectors of the window a tile may read behind its 4 KiB (the launcher needs <= 24: phases < 128 + 256)
 constexpr uint32_t kRoundTripAnySlack = kRoundTripAnySlackVecs * 16;  // bytes a tile's window may read behind the tile's own end
 constexpr uint32_t kRoundTripAnySlab = 5 * 64 * 4;  // LDS bytes: four rows of code dwords + the slack row
-template <int C, int LAUX, int SAUX, bool STRICT>
-__global__ __launch_bounds__(kWave) void round_trip_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back,
-                                                          uint32_t n_tiles, uint32_t phase, uint32_t phase2, uint32_t xs, RoundTripEdgesAny e) {
+template <int C, int LAUX, int SAUX, bool STRICT, bool CHECK>
+__device__ __forceinline__ void round_trip_window_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back, uint32_t n_tiles,
+                                                       uint32_t phase, uint32_t phase2, uint32_t xs, const RoundTripEdgesAny& e, unsigned long long* __restrict__ bad_out) {
     constexpr uint32_t TILE = kRoundTripAnyTile;
     const uint64_t t = tile_of_block<C>(blockIdx.x, n_tiles, xs);
     const __amdgpu_buffer_rsrc_t rin = rsrc_of(in + t * TILE, TILE + kRoundTripAnySlack);
@@ -665,13 +699,43 @@ __global__ __launch_bounds__(kWave) void round_trip_window(const uint8_t* __rest
         __builtin_amdgcn_raw_buffer_store_b32(cp, rpk, j * 4, 0, SAUX);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, dec4(cb)), rbk, j * 16, 0, SAUX);
     }
-    if (blockIdx.x + e.groups >= n_tiles)
-        round_trip_edges_any<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * kWave + lane, (uint64_t)e.groups * kWave);
+    if constexpr (CHECK) {
+        // the tile OWNS the letters it spells out: window bytes [phase, TILE + phase) (n_to_bits_window_body's rule)
+        uint32_t sus = 0, bad = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sus = suspect16<false>(v[u], sus);
+        sus += lane < ((max(phase, phase2) + 15u) >> 4) ? suspect16<false>(v[4], 0u) : 0u;
+        if (__builtin_amdgcn_ballot_w64(sus != 0) != 0) {
+            bad = invalid16_range<false>(v[0], (int)phase - 16 * (int)lane, 16) + invalid16_range<false>(v[4], 0, (int)phase - 16 * (int)lane);
+#pragma unroll
+            for (int u = 1; u < 4; ++u) bad += invalid16<false>(v[u]);
+        }
+        if (blockIdx.x + e.groups >= n_tiles)
+            bad += round_trip_edges_any<STRICT, true>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * kWave + lane, (uint64_t)e.groups * kWave);
+        wave_add_invalid(bad, bad_out);
+    } else {
+        if (blockIdx.x + e.groups >= n_tiles)
+            round_trip_edges_any<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_tiles) * kWave + lane, (uint64_t)e.groups * kWave);
+    }
+}
+template <int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(kWave) void round_trip_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back,
+                                                          uint32_t n_tiles, uint32_t phase, uint32_t phase2, uint32_t xs, RoundTripEdgesAny e) {
+    round_trip_window_body<C, LAUX, SAUX, STRICT, false>(in, packed, back, n_tiles, phase, phase2, xs, e, nullptr);
+}
+template <int C, int LAUX, int SAUX, bool STRICT>
+__global__ __launch_bounds__(kWave) void round_trip_window_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back, uint32_t n_tiles,
+                                                                  uint32_t phase, uint32_t phase2, uint32_t xs, RoundTripEdgesAny e, unsigned long long* __restrict__ bad) {
+    round_trip_window_body<C, LAUX, SAUX, STRICT, true>(in, packed, back, n_tiles, phase, phase2, xs, e, bad);
 }
 // inputs shorter than a tile + slack: the edge body alone, one launch
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void round_trip_generic(RoundTripEdgesAny e) {
     round_trip_edges_any<STRICT>(e, blockIdx.x * (uint64_t)kBlock + threadIdx.x, (uint64_t)gridDim.x * kBlock);
+}
+template <bool STRICT>
+__global__ __launch_bounds__(kBlock) void round_trip_generic_checked(RoundTripEdgesAny e, unsigned long long* __restrict__ bad) {
+    wave_add_invalid(round_trip_edges_any<STRICT, true>(e, blockIdx.x * (uint64_t)kBlock + threadIdx.x, (uint64_t)gridDim.x * kBlock), bad);
 }
 
 // LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,
@@ -716,6 +780,15 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
         out[w] = encode_word_bytes(n, n_len, w, STRICT || w >= lut_from);
 }
 
+template <bool STRICT>
+__global__ __launch_bounds__(kBlock) void n_to_bits_generic_checked(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t* __restrict__ out, uint64_t first_word,
+                                                                    uint64_t n_words, uint64_t lut_from, unsigned long long* __restrict__ bad_out) {
+    uint32_t bad = 0;
+    for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock)
+        out[w] = encode_word_bytes_checked(n, n_len, w, STRICT || w >= lut_from, bad);
+    wave_add_invalid(bad, bad_out);
+}
+
 // STAGED: the host tier's small-call path (hip/host_tier.inc).  The kernel reads the shim's own PINNED
 // staging buffer over PCIe and writes the pinned result buffer: the staging base is 16-B aligned and the
 // host zero-pads the input to a whole word, so a thread takes its 32 nt with two 16-B loads issued
@@ -732,6 +805,23 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_staged(const uint8_t* __rest
         out[w] = (uint64_t)enc16<true>(a) | ((uint64_t)enc16<true>(b) << 32);
     else
         out[w] = (uint64_t)enc16<STRICT>(a) | ((uint64_t)enc16<STRICT>(b) << 32);
+}
+
+// ... and its checked twin (cnt_n_to_bits_checked): the host pads the final word with 'A' -- code 0 like the zero byte, but a
+// letter -- so every byte the kernel sees counts
+template <bool STRICT>
+__global__ __launch_bounds__(kBlock) void n_to_bits_staged_checked(const uint8_t* __restrict__ n, uint64_t* __restrict__ out, uint64_t n_words, uint64_t lut_from,
+                                                                   unsigned long long* __restrict__ bad_out) {
+    const uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x;
+    uint32_t bad = 0;
+    if (w < n_words) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(n + 32 * w);
+        const u32x4 a = p[0], b = p[1];
+        if (!STRICT && w >= lut_from) out[w] = (uint64_t)enc16<true>(a) | ((uint64_t)enc16<true>(b) << 32);
+        else out[w] = (uint64_t)enc16<STRICT>(a) | ((uint64_t)enc16<STRICT>(b) << 32);
+        bad = invalid16<false>(a) + invalid16<false>(b);
+    }
+    wave_add_invalid(bad, bad_out);
 }
 
 // ===========================================================================

@@ -33,11 +33,17 @@ struct VariantDesc {
 //   xcd_shift   log2(hipDeviceAttributeNumberOfXccs) -> the XCD-aware block -> tile maps (0 = identity map when the
 //               count is unknown or not a power of two)
 // Cached per device index; correctness never depends on any of it.
+//   cache_nt    nucleotides whose PACKED form (a quarter of a byte each) fills this device's share of the memory-side Infinity
+//               Cache: 32 MiB per XCD -> 2^27 nt per XCD, 2^30 nt on an SPX MI355X (8 XCDs, 256 MiB).  No HIP attribute reports
+//               the cache; the XCD count does, and a partition of fewer XCDs competes for it with its siblings.  Decode's
+//               launch plan treats calls beyond it as streaming from HBM (device_tier.inc decode_plan).
 struct ChipInfo {
     uint32_t cus, lds_per_cu, xcds, xcd_shift;
+    uint64_t cache_nt;
 };
+inline uint64_t decode_cache_nt_of(uint32_t xcds) { return (uint64_t)(xcds ? xcds : 1) << 27; }
 inline ChipInfo query_chip(int device) {
-    ChipInfo c{0, 0, 0, 0};
+    ChipInfo c{0, 0, 0, 0, 0};
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c.cus = (uint32_t)v;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && v > 0) c.lds_per_cu = (uint32_t)v;
@@ -48,6 +54,7 @@ inline ChipInfo query_chip(int device) {
     if (!c.xcds) c.xcds = 1;
     if ((c.xcds & (c.xcds - 1)) == 0)
         while ((1u << c.xcd_shift) < c.xcds) ++c.xcd_shift;
+    c.cache_nt = decode_cache_nt_of(c.xcds);
     return c;
 }
 inline const ChipInfo& chip_info() {  // of the calling thread's current device
@@ -175,8 +182,10 @@ inline uint32_t edge_groups(uint64_t items, unsigned block, uint64_t n_tiles) {
 // describes (head words in front of d_n, ragged end behind the last tile).  *done_nt = nucleotides the tiles cover
 // (a multiple of the variant's tile); when that is 0 NOTHING is launched and the caller runs the generic kernel.
 // d_n must be 16-B aligned, d_out 4-B (16-B for the lds variant).  Returns 0 / 1 (bad variant).
+// `bad` != nullptr (the *_checked entry points): variant 0's checked twin, *bad += the bytes outside the alphabet.
 template <bool STRICT>
-int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, EncodeEdges e, hipStream_t s, uint64_t* done_nt) {
+int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, EncodeEdges e, hipStream_t s, uint64_t* done_nt, unsigned long long* bad = nullptr) {
+    if (bad) variant = 0;  // the lab's other shapes have no checked twin
     if (variant < 0 || variant >= kNumEncodeVariants) return 1;
     const uint64_t tile = kEncodeVariants[variant].tile_nt;
     const uint64_t total_tiles = n_len / tile;
@@ -194,6 +203,10 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
     const dim3 g(grid_of(n_tiles));
 #define CNT_ENC_STREAM(B, U, C, L, S) \
     hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
+    if (bad) {
+        hipLaunchKernelGGL((n_to_bits_stream_checked<64, 2, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), g, dim3(64), lds, s, in, out, (uint32_t)n_tiles, xs, e, bad);
+        continue;
+    }
     switch (variant) {
         case 0: CNT_ENC_STREAM(64, 2, 1, kNT, kSC0 | kSC1 | kNT); break;
 #ifdef CNT_LAB_VARIANTS
@@ -236,7 +249,7 @@ constexpr uint32_t kWindowEncodeTile = 64 * kWindowEncodeU * 16;
 constexpr uint32_t kEncodeStreamTile = 64 * 2 * 16;  // variant 0's tile: what "a whole number of tiles" means for small inputs
 constexpr uint32_t kWindowEncodeSlack = 144;  // bytes a tile may read behind its end
 template <bool STRICT>
-void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s) {
+void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s, unsigned long long* bad = nullptr) {
     const uint64_t per_launch = max_tiles_per_launch(64);
     const uint32_t lds = std::max(lds_for_cap(12), (kWindowEncodeU + 1) * 256u);  // doubles as the kernel's exchange slab (U + 1 rows of code dwords)
     const uint32_t xs = xcd_shift();
@@ -244,6 +257,10 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
     for (uint64_t first = 0; first < total_tiles; first += per_launch) {
         const uint64_t n_tiles = total_tiles - first < per_launch ? total_tiles - first : per_launch;
         e.groups = first + n_tiles == total_tiles ? edge_groups(encode_edge_items(e), 64, n_tiles) : 0u;
+        if (bad)
+            hipLaunchKernelGGL((n_to_bits_window_checked<kWindowEncodeU, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+                               base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e, bad);
+        else
         hipLaunchKernelGGL((n_to_bits_window<kWindowEncodeU, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e);
     }
@@ -263,7 +280,9 @@ constexpr int kRoundTripDefaultPlan = 3;  // any-alignment launch plan (device_t
 // shape 0 = the default above; shape 1 = the first shipped shape (<64, 2, 2>: two loads, XCD pairs; wants cap 13),
 // two of its 2-KiB tiles per 4-KiB unit -- kept selectable (tuning key "round_trip_shape") for A/B runs
 template <bool STRICT>
-void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, RoundTripEdges e, hipStream_t s) {
+void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, RoundTripEdges e, hipStream_t s,
+                       unsigned long long* bad = nullptr) {
+    if (bad) shape = 0;  // the lab's first shape has no checked twin
     // in 4-KiB units: 2^25 - 64 one-wave workgroups per launch, i.e. ONE launch up to (just under) 2^37 nt -- BASELINE.json
     // configs[3] (2^36 nt) included; the lab's shape 1 spends two workgroups per unit
     const uint64_t per_launch = max_tiles_per_launch(64) / (shape == 1 ? 2 : 1);
@@ -283,6 +302,9 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
             continue;
         }
 #endif
+        if (bad)
+            hipLaunchKernelGGL((round_trip_stream_checked<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e, bad);
+        else
         hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e);
     }
 }
@@ -293,7 +315,8 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
 // Same shape, policies and residency cap as the aligned kernel; the cap's dynamic LDS doubles as the 1280-B exchange slab.
 template <bool STRICT>
 void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap,
-                           RoundTripEdgesAny e, hipStream_t s, int map = 0) {
+                           RoundTripEdgesAny e, hipStream_t s, int map = 0, unsigned long long* bad = nullptr) {
+    if (bad) map = 0;
     const uint64_t per_launch = max_tiles_per_launch(64);  // one workgroup per 4-KiB tile under every map: one launch up to 2^37 nt
     const uint32_t lds = std::max(lds_for_cap(cap), kRoundTripAnySlab);
     const uint32_t xs = xcd_shift();
@@ -315,6 +338,11 @@ void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2,
 #else
         (void)map;
 #endif
+        if (bad)
+            hipLaunchKernelGGL((round_trip_window_checked<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
+                               base + first * kRoundTripAnyTile, packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile,
+                               (uint32_t)n_tiles, phase, phase2, xs, e, bad);
+        else
         hipLaunchKernelGGL((round_trip_window<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kRoundTripAnyTile, packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile,
                            (uint32_t)n_tiles, phase, phase2, xs, e);

@@ -188,6 +188,26 @@ __device__ __forceinline__ uint64_t encode2_word_bytes(const uint8_t* __restrict
     return pack27(c);
 }
 
+// the same, also counting the word's bytes outside ACGTUNacgtun into `bad` (bytes that do not exist count as 'A')
+__device__ __forceinline__ uint64_t encode2_word_bytes_checked(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t w, bool lut, uint32_t& bad) {
+    const uint64_t i0 = w * 27;
+    const int m = (n_len - i0) < 27 ? (int)(n_len - i0) : 27;
+    uint32_t c[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+        uint32_t x = 0, pad = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * d + j;
+            if (k < 27 && k < m) x |= (uint32_t)n[i0 + k] << (8 * j);
+            else pad |= 0x41u << (8 * j);
+        }
+        bad += __builtin_popcount(invalid_mask<true>(x | pad));
+        c[d] = lut ? code5_strict(x) : code5_fast(x);
+    }
+    return pack27(c);
+}
+
 // min(27, len - 27w) letters of packed word w with byte stores; bits beyond `len` are ignored
 __device__ __forceinline__ void decode2_word_bytes(const uint64_t* __restrict__ bits, uint64_t len, uint8_t* __restrict__ out, uint64_t w) {
     const uint64_t i0 = w * 27;
@@ -213,6 +233,15 @@ __global__ __launch_bounds__(kBlock) void n_to_bits2_generic(const uint8_t* __re
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words;
          w += (uint64_t)gridDim.x * kBlock)
         out[w] = encode2_word_bytes(n, n_len, w, STRICT || w >= lut_from);
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(kBlock) void n_to_bits2_generic_checked(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t* __restrict__ out, uint64_t first_word,
+                                                                     uint64_t n_words, uint64_t lut_from, unsigned long long* __restrict__ bad_out) {
+    uint32_t bad = 0;
+    for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock)
+        out[w] = encode2_word_bytes_checked(n, n_len, w, STRICT || w >= lut_from, bad);
+    wave_add_invalid(bad, bad_out);
 }
 
 __global__ __launch_bounds__(kBlock) void bits_to_n2_generic(const uint64_t* __restrict__ bits, uint64_t len,
@@ -245,6 +274,16 @@ __device__ __forceinline__ void encode2_edges(const Encode2Edges& e, uint64_t id
         const uint64_t w = i < e.head_words ? i : e.tail_first + (i - e.head_words);
         e.out[w] = encode2_word_bytes(e.n, e.n_len, w, STRICT || w >= e.lut_from);
     }
+}
+template <bool STRICT>
+__device__ __forceinline__ uint32_t encode2_edges_checked(const Encode2Edges& e, uint64_t idx, uint64_t stride) {
+    const uint64_t items = e.head_words + (e.words - e.tail_first);
+    uint32_t bad = 0;
+    for (uint64_t i = idx; i < items; i += stride) {
+        const uint64_t w = i < e.head_words ? i : e.tail_first + (i - e.head_words);
+        e.out[w] = encode2_word_bytes_checked(e.n, e.n_len, w, STRICT || w >= e.lut_from, bad);
+    }
+    return bad;
 }
 __device__ __forceinline__ void decode2_edges(const Decode2Edges& e, uint64_t idx, uint64_t stride) {
     const uint64_t items = e.head_words + (e.words - e.tail_first);
@@ -297,9 +336,9 @@ __device__ __forceinline__ uint64_t word_from_slab(const uint32_t* my, uint32_t 
 // reads the 8 dwords that cover the 27 bytes of word j*64+l, funnel-shifts them into place,
 // maps 4 bytes at a time to codes with v_perm_b32, and stores one u64 (8 B per lane,
 // 512 B per wave-instruction).
-template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
-__global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                               uint64_t n_wave_tiles, uint32_t xs, Encode2Edges e) {
+template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT, int C, bool CHECK>
+__device__ __forceinline__ void n_to_bits2_wave_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_wave_tiles, uint32_t xs,
+                                                     const Encode2Edges& e, unsigned long long* __restrict__ bad_out) {
     constexpr int TILE_BYTES = kWaveBytes5 * WPL, TILE_VECS = kWaveVecs5 * WPL, TILE_WORDS = kWaveWords5 * WPL;
     __shared__ __attribute__((aligned(16))) uint32_t slab[WAVES][kWaveDwords5 * WPL + 4];
     // readfirstlane makes the wave index provably wave-uniform: without it hipcc wraps every buffer
@@ -331,10 +370,41 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
         const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
         __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
     }
-    if constexpr (WAVES == 1) {  // grid == tiles: the launch's last e.groups workgroups share the edge words
+    if constexpr (CHECK) {
+        // counted on the 16-B vectors as they were loaded -- an exact partition of the tile's bytes, no 27-byte bookkeeping;
+        // the alphabet is the 5-letter codec's: ACGTUNacgtun (n_to_bits2.rs:8-23)
+        static_assert(WAVES == 1, "the checked twin exists for the one-wave shape only");
+        uint32_t sus = 0, bad = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool mine = (i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64);
+            sus += mine ? suspect16<true>(v[i], 0u) : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(sus != 0) != 0) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const bool mine = (i + 1) * 64 <= TILE_VECS || lane < (uint32_t)(TILE_VECS - i * 64);
+                bad += mine ? invalid16<true>(v[i]) : 0u;
+            }
+        }
+        if (blockIdx.x + e.groups >= n_wave_tiles)
+            bad += encode2_edges_checked<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+        wave_add_invalid(bad, bad_out);
+    } else if constexpr (WAVES == 1) {  // grid == tiles: the launch's last e.groups workgroups share the edge words
         if (blockIdx.x + e.groups >= n_wave_tiles)
             encode2_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
     }
+}
+template <int WAVES, int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
+__global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                               uint64_t n_wave_tiles, uint32_t xs, Encode2Edges e) {
+    n_to_bits2_wave_body<WAVES, WPL, LAUX, SAUX, STRICT, C, false>(in, out, n_wave_tiles, xs, e, nullptr);
+}
+// CHECKED (round 6; cnt_n_to_bits2_checked_dev): *bad += the tile's bytes outside ACGTUNacgtun
+template <int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
+__global__ __launch_bounds__(64) void n_to_bits2_wave_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_wave_tiles, uint32_t xs,
+                                                              Encode2Edges e, unsigned long long* __restrict__ bad) {
+    n_to_bits2_wave_body<1, WPL, LAUX, SAUX, STRICT, C, true>(in, out, n_wave_tiles, xs, e, bad);
 }
 
 // WINDOW: the default shape (one wave, 2 words per lane, 3456 B in, 1 KiB out) for an input at
@@ -344,9 +414,9 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 // already picks its 27 bytes out of the slab at an arbitrary byte position, the phase is just an
 // offset into it.  Reads up to 127 B before and 128 B behind the tile (launcher's business).
 constexpr int kWindowSlabDwords5 = 4 * 64 * 4 + 4;
-template <int LAUX, int SAUX, bool STRICT, int C>
-__global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                        uint64_t n_wave_tiles, uint32_t phase, uint32_t xs, Encode2Edges e) {
+template <int LAUX, int SAUX, bool STRICT, int C, bool CHECK>
+__device__ __forceinline__ void n_to_bits2_window_body(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_wave_tiles, uint32_t phase,
+                                                       uint32_t xs, const Encode2Edges& e, unsigned long long* __restrict__ bad_out) {
     constexpr int WPL = 2, TILE_BYTES = kWaveBytes5 * WPL, TILE_WORDS = kWaveWords5 * WPL, WIN_VECS = kWaveVecs5 * WPL + 8;
     constexpr int NLD = (WIN_VECS + 63) / 64;
     // Branch-free on purpose: the fourth 16-B access -- 32 lanes' worth -- is issued by ALL lanes against a descriptor that
@@ -373,8 +443,37 @@ __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restric
         const vu2 w2 = {(uint32_t)word, (uint32_t)(word >> 32)};
         __builtin_amdgcn_raw_buffer_store_b64(w2, rout, (j * 64 + lane) * 8, 0, SAUX);
     }
-    if (blockIdx.x + e.groups >= n_wave_tiles)
-        encode2_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+    if constexpr (CHECK) {
+        // the tile owns window bytes [phase, TILE_BYTES + phase): the first row from `phase` on, the last row up to it
+        // (lanes 32..63 of that row hold the descriptor's zeros and lie behind the range anyway)
+        static_assert(NLD == 4 && TILE_BYTES == 3456, "the ranges below are spelled for four rows over a 3456-byte tile");
+        uint32_t sus = 0, bad = 0;
+#pragma unroll
+        for (int i = 0; i < NLD - 1; ++i) sus = suspect16<true>(v[i], sus);
+        sus += lane < (uint32_t)(WIN_VECS - (NLD - 1) * 64) ? suspect16<true>(v[NLD - 1], 0u) : 0u;
+        if (__builtin_amdgcn_ballot_w64(sus != 0) != 0) {
+            bad = invalid16_range<true>(v[0], (int)phase - 16 * (int)lane, 16) +
+                  invalid16_range<true>(v[NLD - 1], 0, TILE_BYTES + (int)phase - (NLD - 1) * 1024 - 16 * (int)lane);
+#pragma unroll
+            for (int i = 1; i < NLD - 1; ++i) bad += invalid16<true>(v[i]);
+        }
+        if (blockIdx.x + e.groups >= n_wave_tiles)
+            bad += encode2_edges_checked<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+        wave_add_invalid(bad, bad_out);
+    } else {
+        if (blockIdx.x + e.groups >= n_wave_tiles)
+            encode2_edges<STRICT>(e, (uint64_t)(blockIdx.x + e.groups - n_wave_tiles) * 64 + lane, (uint64_t)e.groups * 64);
+    }
+}
+template <int LAUX, int SAUX, bool STRICT, int C>
+__global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        uint64_t n_wave_tiles, uint32_t phase, uint32_t xs, Encode2Edges e) {
+    n_to_bits2_window_body<LAUX, SAUX, STRICT, C, false>(in, out, n_wave_tiles, phase, xs, e, nullptr);
+}
+template <int LAUX, int SAUX, bool STRICT, int C>
+__global__ __launch_bounds__(64) void n_to_bits2_window_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_wave_tiles, uint32_t phase,
+                                                                uint32_t xs, Encode2Edges e, unsigned long long* __restrict__ bad) {
+    n_to_bits2_window_body<LAUX, SAUX, STRICT, C, true>(in, out, n_wave_tiles, phase, xs, e, bad);
 }
 
 // Decode: per round j, lane l loads word j*64+l (8 B, 512 B per wave-instruction), expands

@@ -14,6 +14,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #ifndef CNT_COPY_POOL_TEST_STALL
 #define CNT_COPY_POOL_TEST_STALL(k) ((void)0)
 #endif
@@ -108,6 +111,17 @@ class CopyPool {
         limit_ = n;
         if (started_) stop();
     }
+    // Where the HELPERS run (the caller is never moved): the CPUs of the NUMA node the GPU hangs off, so that the staging
+    // copies' far end -- the pinned ring, which lives there -- is local to most of the team (host tier, CNT_HOST_NUMA); nullptr =
+    // wherever the caller's own mask lets them.  Takes effect at the next copy() (a running team is stopped and restarts).
+    void set_cpus(const cpu_set_t* cpus) {
+        const bool want = cpus != nullptr;
+        if (want == have_cpus_ && (!want || CPU_EQUAL(cpus, &cpus_))) return;
+        have_cpus_ = want;
+        if (want) cpus_ = *cpus;
+        if (started_) stop();
+    }
+    int pinned_cpus() const { return have_cpus_ ? CPU_COUNT(&cpus_) : 0; }
     // the warm-copy team = what CNT_HOST_COPY_THREADS / the sharded budget count (the caller is one of them); threads that
     // EXIST besides the caller: spawned() -- up to 2 x team - 1, the second half only works on copies into fresh pages
     int size() const { return started_ ? team_ : 0; }
@@ -166,6 +180,7 @@ class CopyPool {
         }
     }
     void run(int k, uint64_t seen) {
+        if (have_cpus_) (void)pthread_setaffinity_np(pthread_self(), sizeof cpus_, &cpus_);  // set before the team starts, never changed under it
         for (;;) {
             // wait for a new generation: spin first (the next copy of a pipelined call is microseconds away), then sleep
             const auto t0 = std::chrono::steady_clock::now();
@@ -209,6 +224,7 @@ class CopyPool {
     std::atomic<int> job_team_{0}, sleepers_{0};
     std::atomic<bool> stop_{false};
     int n_threads_ = 1, team_ = 1, limit_ = 0;
-    bool started_ = false;
+    bool started_ = false, have_cpus_ = false;
+    cpu_set_t cpus_;
     std::chrono::steady_clock::time_point last_mid_copy_{};  // when the calling thread's previous lone mid-size copy ended (a pool has one caller)
 };

@@ -37,6 +37,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include "codec2_kernels.hpp"
@@ -101,8 +102,16 @@ std::atomic<int> g_round_trip_plan{kRoundTripDefaultPlan};  // pricing of the an
 inline int tune_round_trip_plan() { return g_round_trip_plan.load(std::memory_order_relaxed); }
 std::atomic<int> g_decode_rot{-1};  // further 4-KiB output pages peeled in front of decode's tiles (device_tier.inc decode_turn_pages): -1 the shipped rule, 0..3 forced, 10 / 11 the two candidate rules
 inline int tune_decode_rot() { return g_decode_rot.load(std::memory_order_relaxed); }
-std::atomic<int> g_decode_window{1};  // 1 (shipped): bits_to_n_window whenever the packed stream is off its lines or dwords; 0: round 4's stream / shifted kernels
+std::atomic<int> g_decode_window{1};  // 1 (shipped): bits_to_n_window for calls past the Infinity Cache whose packed stream is off its lines or dwords; 0: round 4's stream / shifted kernels
 inline bool tune_decode_window() { return g_decode_window.load(std::memory_order_relaxed) != 0; }
+// log2 of the size (nt) beyond which decode plans for a packed stream that no longer fits the Infinity Cache: -1 = the device's
+// (chip_info().cache_nt, the shipped rule), 0..40 forced -- 0 lets a 2^20-nt call walk the past-the-cache plan (turn placement +
+// bits_to_n_window) at every packed phase with guard pages around it (its only coverage used to need 4 GiB of HBM)
+std::atomic<int> g_decode_cache_log2{-1};
+inline uint64_t decode_cache_nt() {
+    const int o = g_decode_cache_log2.load(std::memory_order_relaxed);
+    return o >= 0 ? (uint64_t)1 << o : chip_info().cache_nt;
+}
 #else
 constexpr int tune_encode() { return 0; }
 constexpr int tune_decode() { return 0; }
@@ -115,6 +124,7 @@ constexpr int tune_round_trip_window_map() { return 0; }
 constexpr int tune_round_trip_plan() { return kRoundTripDefaultPlan; }
 constexpr int tune_decode_rot() { return -1; }
 constexpr bool tune_decode_window() { return true; }
+inline uint64_t decode_cache_nt() { return chip_info().cache_nt; }
 #endif
 
 inline unsigned generic_grid(uint64_t items) {
@@ -193,6 +203,17 @@ int cnt_device_numa_node(int device, int* node) {
     return CNT_OK;
 }
 
+// what the calling thread's host tier is bound to on its current device (after its first host-tier call there)
+int cnt_host_tier_info(int* device, int* numa_node, int* helper_cpus, int* staging_node) {
+    DevCtx* c = nullptr;
+    CNT_TRY(t_ctx.get(&c));
+    if (device) *device = c->device;
+    if (numa_node) *numa_node = c->numa.node;
+    if (helper_cpus) *helper_cpus = t_ctx.pool.pinned_cpus();
+    if (staging_node) *staging_node = numa_node_of_page(c->h_in[0]);
+    return CNT_OK;
+}
+
 static int release_thread_ctx() {
     t_queues.release();
     t_ctx.pool.stop();
@@ -220,6 +241,11 @@ int cnt_n_to_bits_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_w
 int cnt_n_to_bits(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words) {
     return cnt_n_to_bits_ex(n, n_len, out, out_words, 0);
 }
+// the same call, also counting the bytes outside ACGTUacgtu -- in the encode kernels' own pass over the data
+int cnt_n_to_bits_checked(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags, uint64_t* invalid) {
+    if (!invalid) return CNT_EINVAL;
+    return host_encode(n, n_len, out, out_words, flags, lut_from_of(n_len, flags, 32), 32, kChunkNt, encode_impl, invalid);
+}
 int cnt_bits_to_n(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
     return host_decode(bits, words, len, out, 32, kChunkNt, decode_dev);
 }
@@ -228,6 +254,10 @@ int cnt_n_to_bits2_ex(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_
 }
 int cnt_n_to_bits2(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words) {
     return cnt_n_to_bits2_ex(n, n_len, out, out_words, 0);
+}
+int cnt_n_to_bits2_checked(const uint8_t* n, size_t n_len, uint64_t* out, size_t out_words, unsigned flags, uint64_t* invalid) {
+    if (!invalid) return CNT_EINVAL;
+    return host_encode(n, n_len, out, out_words, flags, lut_from_of(n_len, flags, 27), 27, kChunkNt5, encode2_impl, invalid);
 }
 int cnt_bits_to_n2(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
     return host_decode(bits, words, len, out, 27, kChunkNt5, decode2_dev);
@@ -309,6 +339,19 @@ int cnt_sharded_dev_open_on_streams(int ndev, void* const* streams, unsigned fla
     *queue = q;
     return rc;
 }
+int cnt_sharded_dev_open_on_devices(int ndev, const int* devices, unsigned flags, void** queue) {
+    ShardQueue* q = nullptr;
+    if (!queue) return CNT_EINVAL;
+    const int rc = shard_queue_open(ndev, flags, &q, nullptr, false, devices, true);
+    *queue = q;
+    return rc;
+}
+int cnt_sharded_dev_device(void* queue, int k, int* device) {
+    ShardQueue* q = shard_queue_of(queue);
+    if (!q || !device || k < 0 || k >= q->ndev) return CNT_EINVAL;
+    *device = q->device_of(k);
+    return CNT_OK;
+}
 int cnt_sharded_dev_wait_event(void* queue, int k, void* event) { return shard_queue_event(queue, k, event, false); }
 int cnt_sharded_dev_record_event(void* queue, int k, void* event) { return shard_queue_event(queue, k, event, true); }
 int cnt_sharded_dev_close(void* queue) { return shard_queue_close(queue); }
@@ -351,6 +394,27 @@ int cnt_round_trip_sharded_dev_enqueue(void* queue, const void* const* d_n, cons
 int cnt_n_to_bits2_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags) {
     return queue_encode(queue, d_n, n_len, d_out, out_words, flags, encode2_dev);
 }
+// ... and the checked forms: d_invalid_count[k] is a device u64 ON SHARD k's DEVICE that the caller zeroes; shard k's op adds to it
+static int queue_encode_checked(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags,
+                                void* const* d_invalid, int (*fn)(const void*, size_t, void*, size_t, unsigned, void*, hipStream_t)) {
+    if (!d_n || !n_len || !d_out || !out_words || !d_invalid) return CNT_EINVAL;
+    return shard_queue_enqueue(queue, [&](int k, hipStream_t s) { return fn(d_n[k], n_len[k], d_out[k], out_words[k], flags, d_invalid[k], s); });
+}
+int cnt_n_to_bits_checked_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags,
+                                              void* const* d_invalid_count) {
+    return queue_encode_checked(queue, d_n, n_len, d_out, out_words, flags, d_invalid_count, encode_checked_dev);
+}
+int cnt_n_to_bits2_checked_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_out, const size_t* out_words, unsigned flags,
+                                               void* const* d_invalid_count) {
+    return queue_encode_checked(queue, d_n, n_len, d_out, out_words, flags, d_invalid_count, encode2_checked_dev);
+}
+int cnt_round_trip_checked_sharded_dev_enqueue(void* queue, const void* const* d_n, const size_t* n_len, void* const* d_bits, const size_t* out_words,
+                                               void* const* d_back, unsigned flags, void* const* d_invalid_count) {
+    if (!d_n || !n_len || !d_bits || !out_words || !d_back || !d_invalid_count) return CNT_EINVAL;
+    return shard_queue_enqueue(queue, [&](int k, hipStream_t s) {
+        return round_trip_checked_dev(d_n[k], n_len[k], d_bits[k], out_words[k], d_back[k], flags, d_invalid_count[k], s);
+    });
+}
 int cnt_bits_to_n2_sharded_dev_enqueue(void* queue, const void* const* d_bits, const size_t* words, const size_t* len, void* const* d_out, unsigned flags) {
     return queue_decode(queue, d_bits, words, len, d_out, flags, decode2_dev);
 }
@@ -370,6 +434,16 @@ int cnt_n_to_bits2_dev(const void* d_n, size_t n_len, void* d_out, size_t out_wo
 }
 int cnt_bits_to_n2_dev(const void* d_bits, size_t words, size_t len, void* d_out, unsigned flags, void* stream) {
     return decode2_dev(d_bits, words, len, d_out, flags, static_cast<hipStream_t>(stream));
+}
+// encode + validity count in ONE pass over the ASCII (1.25 B/nt instead of the 2.25 of cnt_validate_dev + cnt_n_to_bits_dev)
+int cnt_n_to_bits_checked_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, void* d_invalid_count, void* stream) {
+    return encode_checked_dev(d_n, n_len, d_out, out_words, flags, d_invalid_count, static_cast<hipStream_t>(stream));
+}
+int cnt_n_to_bits2_checked_dev(const void* d_n, size_t n_len, void* d_out, size_t out_words, unsigned flags, void* d_invalid_count, void* stream) {
+    return encode2_checked_dev(d_n, n_len, d_out, out_words, flags, d_invalid_count, static_cast<hipStream_t>(stream));
+}
+int cnt_round_trip_checked_dev(const void* d_n, size_t n_len, void* d_bits, size_t out_words, void* d_back, unsigned flags, void* d_invalid_count, void* stream) {
+    return round_trip_checked_dev(d_n, n_len, d_bits, out_words, d_back, flags, d_invalid_count, static_cast<hipStream_t>(stream));
 }
 
 // ---- device memory for callers that do not link HIP themselves (Rust / C / C++ benches) ----------
@@ -464,6 +538,9 @@ int cnt_set_tuning(const char* key, int value) {
     } else if (!strcmp(key, "decode_window")) {
         if (value < 0 || value > 1) return CNT_EINVAL;
         g_decode_window.store(value);
+    } else if (!strcmp(key, "decode_cache_log2")) {
+        if (value < -1 || value > 40) return CNT_EINVAL;
+        g_decode_cache_log2.store(value);
     } else if (!strcmp(key, "decode_rot")) {
         if (value < -1 || (value > 3 && value != 10 && value != 11)) return CNT_EINVAL;
         g_decode_rot.store(value);
@@ -519,6 +596,7 @@ int cnt_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "launch_tiles")) *value = launch_tiles_override().load();
     else if (!strcmp(key, "decode_rot")) *value = g_decode_rot.load();
     else if (!strcmp(key, "decode_window")) *value = g_decode_window.load();
+    else if (!strcmp(key, "decode_cache_log2")) *value = g_decode_cache_log2.load();
     else if (!strcmp(key, "reduce_xi")) *value = g_reduce_xi.load();
     else if (!strcmp(key, "hamming_order")) *value = g_hamming_order.load();
     else if (!strcmp(key, "reduce_fallbacks")) *value = g_reduce_fallbacks.load();
@@ -539,6 +617,14 @@ int cnt_chip_info(int device, int* compute_units, int* lds_bytes_per_cu, int* xc
     if (compute_units) *compute_units = (int)c.cus;
     if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)c.lds_per_cu;
     if (xcds) *xcds = (int)c.xcds;
+    return CNT_OK;
+}
+
+int cnt_chip_cache_nt(int device, uint64_t* nt) {
+    int count = 0;
+    if (!nt) return CNT_EINVAL;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CNT_ENODEV;
+    *nt = query_chip(device).cache_nt;
     return CNT_OK;
 }
 
@@ -599,9 +685,9 @@ int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uin
     out[7] = kRoundTripAnySlackVecs;
     return CNT_OK;
 }
-int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t* out) {
-    if (!out || (a_bits & 7)) return CNT_EINVAL;
-    const DecodePlan p = decode_plan((uintptr_t)a_bits, (uintptr_t)a_out, len, tune_decode_rot(), tune_decode_window());
+int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t cache_nt, uint64_t* out) {
+    if (!out || (a_bits & 7) || !cache_nt) return CNT_EINVAL;
+    const DecodePlan p = decode_plan((uintptr_t)a_bits, (uintptr_t)a_out, len, tune_decode_rot(), tune_decode_window(), cache_nt);
     out[0] = p.head;                                   // nucleotides in front of the first tile (edge items)
     out[1] = (a_out + p.head) & 4095;                  // the first tile's output byte inside its page (0 for len >= 2^20)
     out[2] = (a_bits + 4 * (p.head >> 4)) & 4095;      // the first tile's packed byte inside its page: where every XCD turn starts

@@ -101,14 +101,27 @@ int cnt_shutdown(void);
  * words.  Synchronous: chunked, double-buffered H2D -> kernel -> D2H inside. */
 int cnt_n_to_bits(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words);
 int cnt_n_to_bits_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, unsigned flags);
+/* The same encode, VALIDATED in the same pass: *invalid = the number of bytes of `n` outside ACGTUacgtu (cnt_validate's
+ * count), found by the encode kernels while they pack -- the words are what cnt_n_to_bits_ex writes, valid or not.  The
+ * reference's BYTE_LUT encodes every other byte as 0 without a word (n_to_bits.rs:8-21,42) and its README points at a separate
+ * validity check (README.md:23): this is both in one trip over the data.  flags as cnt_n_to_bits_ex; `invalid` is never NULL. */
+int cnt_n_to_bits_checked(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, unsigned flags, uint64_t *invalid);
 /* Replaces bits_to_n_{lut,shuffle,pdep,clmul}(bits, len) (n_to_bits.rs:51,265,
  * 309,346).  Writes exactly `len` bytes to `out` (the Vec's length). */
 int cnt_bits_to_n(const uint64_t *bits, size_t words, size_t len, uint8_t *out);
 /* Replaces n_to_bits2_{lut,pext}(n) (n_to_bits2.rs:37,118); _ex takes the encode flags above. */
 int cnt_n_to_bits2(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words);
 int cnt_n_to_bits2_ex(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, unsigned flags);
+/* ... and validated: *invalid = bytes outside the 5-letter codec's alphabet ACGTUNacgtun (n_to_bits2.rs:8-23). */
+int cnt_n_to_bits2_checked(const uint8_t *n, size_t n_len, uint64_t *out, size_t out_words, unsigned flags, uint64_t *invalid);
 /* Replaces bits_to_n2_{lut,pdep}(bits, len) (n_to_bits2.rs:78,196). */
 int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out);
+
+/* Where the calling thread's host tier sits on its current device (any pointer may be NULL): the device index, the NUMA node
+ * that GPU hangs off (-1 = the platform does not say), the CPUs its staging-copy helpers are pinned to (0 = not pinned: placement
+ * off or unknown) and the node that holds the first page of its pinned staging ring (-1 = not allocated yet, or the kernel does
+ * not report nodes for that mapping).  The calling thread itself is never moved.  See CNT_HOST_NUMA below. */
+int cnt_host_tier_info(int *device, int *numa_node, int *helper_cpus, int *staging_node);
 
 /* ---- multi-GPU host tier: contiguous-chunk sharding, no collective ------------ */
 /* Same contracts as above; the buffer is cut into `ndev` contiguous chunks on
@@ -193,12 +206,25 @@ int cnt_bits_to_n2_sharded_dev(const void *const *d_bits, const size_t *words, c
  *                                 on that stream before and after -- the ordering the single-GPU *_dev entry points have
  *                                 by taking the caller's stream.  close() neither synchronises nor destroys adopted
  *                                 streams; wait() synchronises them.
+ *                                 The queue ASKS each stream which device it belongs to (hipStreamGetDevice) and makes THAT
+ *                                 device current for everything it does for the shard -- the position k says nothing; streams in
+ *                                 any order, several on one device, a subset of the devices are all fine, and a handle that is
+ *                                 not a stream of a visible device is CNT_EINVAL.  ndev <= 64.
+ *   cnt_sharded_dev_open_on_devices  library-owned streams on an explicit device list: shard k runs on devices[k] (ndev >= 1
+ *                                 entries, <= 64; any subset, order or repetition of the visible devices -- two shards on one
+ *                                 device simply share it).  A negative entry is CNT_EINVAL, one >= the visible count CNT_ENODEV.
+ *   cnt_sharded_dev_device        where shard k runs: the device index the queue makes current for it (what the caller's buffers
+ *                                 for shard k must live on).
  * With CNT_QUEUE_TIMED the time a shard's stream spends waiting for a caller event counts into the op enqueued after it,
- * unless that op is the first of its batch (the batch's start event is recorded behind the wait). */
+ * unless that op is the first of its batch (the batch's start event is recorded behind the wait).  An enqueue that fails
+ * after some shards have been queued leaves work between two of the batch's events that is in no op: the times of that batch
+ * are withdrawn (wait reports zeros, cnt_sharded_dev_op_ms is CNT_EINVAL) rather than silently including it. */
 #define CNT_QUEUE_TIMED 0x1u
 #define CNT_QUEUE_MAX_TIMED_OPS 4096
 int cnt_sharded_dev_open(int ndev, unsigned flags, void **queue);
 int cnt_sharded_dev_open_on_streams(int ndev, void *const *streams, unsigned flags, void **queue);
+int cnt_sharded_dev_open_on_devices(int ndev, const int *devices, unsigned flags, void **queue);
+int cnt_sharded_dev_device(void *queue, int k, int *device);
 int cnt_sharded_dev_wait_event(void *queue, int k, void *event);
 int cnt_sharded_dev_record_event(void *queue, int k, void *event);
 int cnt_sharded_dev_close(void *queue);
@@ -211,6 +237,14 @@ int cnt_round_trip_sharded_dev_enqueue(void *queue, const void *const *d_n, cons
                                        void *const *d_back, unsigned flags);
 int cnt_n_to_bits2_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags);
 int cnt_bits_to_n2_sharded_dev_enqueue(void *queue, const void *const *d_bits, const size_t *words, const size_t *len, void *const *d_out, unsigned flags);
+/* the validated forms (cnt_n_to_bits_checked_dev & co. below) on every shard: d_invalid_count[k] is a device u64 ON SHARD k's
+ * DEVICE, zeroed by the caller; shard k's op adds its count to it */
+int cnt_n_to_bits_checked_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags,
+                                              void *const *d_invalid_count);
+int cnt_n_to_bits2_checked_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_out, const size_t *out_words, unsigned flags,
+                                               void *const *d_invalid_count);
+int cnt_round_trip_checked_sharded_dev_enqueue(void *queue, const void *const *d_n, const size_t *n_len, void *const *d_bits, const size_t *out_words,
+                                               void *const *d_back, unsigned flags, void *const *d_invalid_count);
 int cnt_sharded_dev_wait(void *queue, float *shard_ms);
 int cnt_sharded_dev_op_ms(void *queue, size_t op, float *shard_ms);
 
@@ -240,6 +274,22 @@ int cnt_n_to_bits2_dev(const void *d_n, size_t n_len, void *d_out, size_t out_wo
  * aligned speed). */
 int cnt_round_trip_dev(const void *d_n, size_t n_len, void *d_bits, size_t out_words, void *d_back, unsigned flags, void *stream);
 int cnt_bits_to_n2_dev(const void *d_bits, size_t words, size_t len, void *d_out, unsigned flags, void *stream);
+
+/* ENCODE AND VALIDATE IN ONE PASS.  The reference's BYTE_LUT silently encodes every byte outside the alphabet as 0
+ * (n_to_bits.rs:8-21,42; its README points at a separate check, README.md:23), and so far so did this library: a caller who
+ * wanted to KNOW ran cnt_validate_dev (1 B/nt) and then the encoder (1.25 B/nt).  The *_checked entry points do what the
+ * unchecked ones do -- same words, same flags, same alignment freedom, one launch, enqueue-only, no allocation, graph-capturable --
+ * and add to *d_invalid_count (a device u64 on the current device, 8-byte aligned, ZEROED BY THE CALLER like the counters of
+ * cnt_validate_dev / cnt_hamming_dev; never NULL) the number of input bytes outside the codec's alphabet:
+ *     cnt_n_to_bits_checked_dev, cnt_round_trip_checked_dev   ACGTUacgtu       == cnt_validate_dev(d_n, n_len, 0, ...)
+ *     cnt_n_to_bits2_checked_dev                              ACGTUNacgtun     == cnt_validate_dev(d_n, n_len, CNT_ALLOW_N, ...)
+ * whatever the encode flags say about how such bytes are ENCODED.  1.25 B/nt of HBM traffic instead of 2.25 for the validated
+ * encode.  Cost on clean data: a byte-wise |letter - expected| sum per tile (v_sad_u8) and one wave-uniform branch behind the
+ * tile's stores; a wave that saw anything recounts its registers exactly and issues ONE atomic -- so a buffer in which every
+ * 2-KiB tile holds a stray byte (a FASTA file with its line feeds, say) costs one atomic per tile on a single counter. */
+int cnt_n_to_bits_checked_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *d_invalid_count, void *stream);
+int cnt_n_to_bits2_checked_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *d_invalid_count, void *stream);
+int cnt_round_trip_checked_dev(const void *d_n, size_t n_len, void *d_bits, size_t out_words, void *d_back, unsigned flags, void *d_invalid_count, void *stream);
 
 /* Device memory for callers that do not link the HIP runtime themselves (the Rust / C++ bench rows
  * that drive the device tier): hipMalloc / hipFree / synchronous hipMemcpy / hipStreamSynchronize on
@@ -317,6 +367,11 @@ const char *cnt_tuning_name(const char *key, int value);
  * partitioned modes and other CDNA parts answer differently, and the residency caps, the persistent
  * reductions' grids and the XCD-aware tile maps follow).  Any pointer may be NULL. */
 int cnt_chip_info(int device, int *compute_units, int *lds_bytes_per_cu, int *xcds);
+/* The size (nucleotides) beyond which cnt_bits_to_n_dev treats a call's packed stream as streaming from HBM instead of living in
+ * the memory-side Infinity Cache: 2^27 nt (32 MiB of packed words) per XCD of the device -- 2^30 nt on an SPX MI355X (8 XCDs,
+ * 256 MiB), less on a partitioned-mode device, which shares the cache with its siblings.  Only decode's launch plan off the
+ * 128-byte grid depends on it (speed, never results). */
+int cnt_chip_cache_nt(int device, uint64_t *nt);
 
 /* Debug aid for callers of the *_dev entry points, which take raw pointers and only enqueue: a host pointer or another
  * device's memory there is a GPU page fault (a process abort) when the kernel runs, not an error code.  CNT_OK if
@@ -344,6 +399,9 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                Vec / np.empty is then faulted in, and later freed by the caller, in 2-MiB units (1-GiB
  *                                decode into a fresh malloc: 150 -> 72-91 ms per call); a warm output (reused buffer, the
  *                                `_into` forms) is never advised, its VMA flags and RSS stay as the caller made them
+ *   CNT_HOST_NUMA=0              do NOT place the single-GPU host tier by the GPU's NUMA node.  The default reads the node from
+ *                                sysfs, allocates the pinned staging ring from a short-lived thread pinned to its CPUs and pins the
+ *                                copy team's helper threads there; the calling thread is never moved (cnt_host_tier_info reports)
  *   CNT_SHARD_NUMA=0             sharded tier: do not pin workers to their GPU's NUMA node
  *   CNT_SHARD_COPY_THREADS_TOTAL sharded tier: staging-copy teams summed over all devices (default 32: 8 shards -> teams of
  *                                4); as above the threads that exist are up to twice that minus one per shard */
@@ -374,13 +432,14 @@ int cnt_test_advise_output(void *out, size_t bytes);
  * the slab, every letter and packed dword owned by exactly one of tiles / edge items, tiles off the final partial word
  * under CNT_TAIL_LUT. */
 int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uint64_t n_len, unsigned flags, uint64_t *out);
-/* The launch plan cnt_bits_to_n_dev would use for buffers at these ADDRESSES (nothing is dereferenced, no device needed): out[0] =
+/* The launch plan cnt_bits_to_n_dev would use for buffers at these ADDRESSES on a device whose cnt_chip_cache_nt is `cache_nt`
+ * (nothing is dereferenced, no device needed): out[0] =
  * nucleotides in front of the first tile, out[1] = the first tile's output byte inside its 4-KiB page, out[2] = its packed byte
- * inside ITS page (where every XCD turn of four tiles starts: for calls of more than 2^30 nt the launcher peels up to three
+ * inside ITS page (where every XCD turn of four tiles starts: for calls of more than cache_nt nt the launcher peels up to three
  * further output pages so that this lies within 512 bytes of a page boundary of the packed buffer), out[3] = the packed
  * stream's bit phase, out[4] = its dword phase against the 128-byte line, out[5] = 1 if the window kernel takes the call
  * (either phase non-zero), out[6] = whole tiles.  out holds 7 entries. */
-int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t *out);
+int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t cache_nt, uint64_t *out);
 #endif /* CNT_TEST_HOOKS */
 
 #ifdef __cplusplus

@@ -17,6 +17,8 @@ extern "C" {
     fn cnt_words_for(n_len: usize) -> usize;
     fn cnt_words2_for(n_len: usize) -> usize;
     fn cnt_n_to_bits_ex(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, flags: c_uint) -> c_int;
+    fn cnt_n_to_bits_checked(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, flags: c_uint, invalid: *mut u64) -> c_int;
+    fn cnt_n_to_bits2_checked(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, flags: c_uint, invalid: *mut u64) -> c_int;
     fn cnt_bits_to_n(bits: *const u64, words: usize, len: usize, out: *mut u8) -> c_int;
     fn cnt_n_to_bits2(n: *const u8, n_len: usize, out: *mut u64, out_words: usize) -> c_int;
     fn cnt_n_to_bits2_ex(n: *const u8, n_len: usize, out: *mut u64, out_words: usize, flags: c_uint) -> c_int;
@@ -28,6 +30,7 @@ extern "C" {
     // device tier (enqueue-only) + the device-memory helpers a caller without HIP bindings needs
     fn cnt_n_to_bits_dev(d_n: *const c_void, n_len: usize, d_out: *mut c_void, out_words: usize, flags: c_uint, stream: *mut c_void) -> c_int;
     fn cnt_bits_to_n_dev(d_bits: *const c_void, words: usize, len: usize, d_out: *mut c_void, flags: c_uint, stream: *mut c_void) -> c_int;
+    fn cnt_n_to_bits_checked_dev(d_n: *const c_void, n_len: usize, d_out: *mut c_void, out_words: usize, flags: c_uint, d_invalid_count: *mut c_void, stream: *mut c_void) -> c_int;
     fn cnt_dev_alloc(d_ptr: *mut *mut c_void, bytes: usize) -> c_int;
     fn cnt_dev_free(d_ptr: *mut c_void) -> c_int;
     fn cnt_dev_upload(d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
@@ -39,12 +42,15 @@ extern "C" {
     // multi-GPU device tier, enqueue-only: one library stream per shard, any number of ops queued ahead, one wait
     fn cnt_sharded_dev_open(ndev: c_int, flags: c_uint, queue: *mut *mut c_void) -> c_int;
     fn cnt_sharded_dev_open_on_streams(ndev: c_int, streams: *const *mut c_void, flags: c_uint, queue: *mut *mut c_void) -> c_int;
+    fn cnt_sharded_dev_open_on_devices(ndev: c_int, devices: *const c_int, flags: c_uint, queue: *mut *mut c_void) -> c_int;
+    fn cnt_sharded_dev_device(queue: *mut c_void, k: c_int, device: *mut c_int) -> c_int;
     fn cnt_sharded_dev_shards(queue: *mut c_void, ndev: *mut c_int) -> c_int;
     fn cnt_sharded_dev_wait_event(queue: *mut c_void, k: c_int, event: *mut c_void) -> c_int;
     fn cnt_sharded_dev_record_event(queue: *mut c_void, k: c_int, event: *mut c_void) -> c_int;
     fn cnt_sharded_dev_close(queue: *mut c_void) -> c_int;
     fn cnt_n_to_bits_sharded_dev_enqueue(queue: *mut c_void, d_n: *const *const c_void, n_len: *const usize, d_out: *const *mut c_void, out_words: *const usize, flags: c_uint) -> c_int;
     fn cnt_bits_to_n_sharded_dev_enqueue(queue: *mut c_void, d_bits: *const *const c_void, words: *const usize, len: *const usize, d_out: *const *mut c_void, flags: c_uint) -> c_int;
+    fn cnt_n_to_bits_checked_sharded_dev_enqueue(queue: *mut c_void, d_n: *const *const c_void, n_len: *const usize, d_out: *const *mut c_void, out_words: *const usize, flags: c_uint, d_invalid_count: *const *mut c_void) -> c_int;
     fn cnt_sharded_dev_wait(queue: *mut c_void, shard_ms: *mut f32) -> c_int;
     fn cnt_sharded_dev_op_ms(queue: *mut c_void, op: usize, shard_ms: *mut f32) -> c_int;
     // packed-domain operations (host tier): what the reference's README points to, on the packed words
@@ -101,6 +107,30 @@ pub fn n_to_bits_hip_simd_exact(n: &[u8]) -> Vec<u64> {
     res
 }
 
+/// `n_to_bits_hip` VALIDATED in the same pass over the data: the second value is the number of bytes of `n` outside
+/// `ACGTUacgtu` -- what `BYTE_LUT` turns into code 0 without a word (`n_to_bits.rs:8-21,42`; the reference's README points at a
+/// separate check, `README.md:23`).  The words are `n_to_bits_hip`'s whatever the count says.
+pub fn n_to_bits_hip_checked(n: &[u8]) -> (Vec<u64>, u64) {
+    let words = unsafe { cnt_words_for(n.len()) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    let mut invalid: u64 = 0;
+    unsafe {
+        check(cnt_n_to_bits_checked(n.as_ptr(), n.len(), res.as_mut_ptr(), words, 0, &mut invalid));
+        res.set_len(words);
+    }
+    (res, invalid)
+}
+
+/// The validated encode as a `Result`: `Err(count)` if `n` holds `count > 0` bytes that are not nucleotides.
+pub fn try_n_to_bits_hip(n: &[u8]) -> Result<Vec<u64>, u64> {
+    let (res, invalid) = n_to_bits_hip_checked(n);
+    if invalid == 0 {
+        Ok(res)
+    } else {
+        Err(invalid)
+    }
+}
+
 /// Decode pairs of bits from packed 64-bit integers on the GPU (`n_to_bits.rs:51`).
 pub fn bits_to_n_hip(bits: &[u64], len: usize) -> Vec<u8> {
     if len > (bits.len() << 5) {
@@ -123,6 +153,18 @@ pub fn n_to_bits2_hip(n: &[u8]) -> Vec<u64> {
         res.set_len(words);
     }
     res
+}
+
+/// `n_to_bits2_hip` validated in the same pass: the second value counts the bytes outside `ACGTUNacgtun` (`n_to_bits2.rs:8-23`).
+pub fn n_to_bits2_hip_checked(n: &[u8]) -> (Vec<u64>, u64) {
+    let words = unsafe { cnt_words2_for(n.len()) };
+    let mut res: Vec<u64> = Vec::with_capacity(words);
+    let mut invalid: u64 = 0;
+    unsafe {
+        check(cnt_n_to_bits2_checked(n.as_ptr(), n.len(), res.as_mut_ptr(), words, 0, &mut invalid));
+        res.set_len(words);
+    }
+    (res, invalid)
 }
 
 /// `n_to_bits2_pext` to the letter on any bytes: its low-3-bit table up to word `(len - 5) / 27`, `BYTE_LUT` from there
@@ -346,6 +388,13 @@ pub fn n_to_bits_hip_dev(d_n: &DeviceBuffer, n_len: usize, d_out: &DeviceBuffer)
     unsafe { check(cnt_n_to_bits_dev(d_n.ptr, n_len, d_out.ptr, d_out.bytes / 8, 0, std::ptr::null_mut())) };
 }
 
+/// Encode + validity count in ONE pass over the resident ASCII: the launch ADDS the number of bytes outside `ACGTUacgtu`
+/// to the `u64` at the start of `d_invalid` (>= 8 bytes of device memory, zeroed by the caller).
+pub fn n_to_bits_hip_checked_dev(d_n: &DeviceBuffer, n_len: usize, d_out: &DeviceBuffer, d_invalid: &DeviceBuffer) {
+    assert!(n_len <= d_n.bytes && d_invalid.bytes >= 8);
+    unsafe { check(cnt_n_to_bits_checked_dev(d_n.ptr, n_len, d_out.ptr, d_out.bytes / 8, 0, d_invalid.ptr, std::ptr::null_mut())) };
+}
+
 /// Enqueue the decode of `len` nucleotides from `words` device-resident words into `d_out` (>= `len` bytes).
 pub fn bits_to_n_hip_dev(d_bits: &DeviceBuffer, words: usize, len: usize, d_out: &DeviceBuffer) {
     if len > (words << 5) {
@@ -389,6 +438,23 @@ impl ShardedDevQueue {
         ShardedDevQueue::adopt(handle)
     }
 
+    /// Library-owned streams on an explicit device list: shard `k` runs on `devices[k]` (any subset, order or repetition of
+    /// the visible devices).
+    pub fn on_devices(devices: &[i32], timed: bool) -> ShardedDevQueue {
+        assert!(!devices.is_empty() && devices.len() <= c_int::MAX as usize);
+        let mut handle: *mut c_void = std::ptr::null_mut();
+        unsafe { check(cnt_sharded_dev_open_on_devices(devices.len() as c_int, devices.as_ptr(), if timed { CNT_QUEUE_TIMED } else { 0 }, &mut handle)) };
+        ShardedDevQueue::adopt(handle)
+    }
+
+    /// The device the queue runs shard `k` on -- for adopted streams what the STREAM says, not `k`.
+    pub fn device(&self, k: usize) -> i32 {
+        assert!(k < self.ndev);
+        let mut d: c_int = -1;
+        unsafe { check(cnt_sharded_dev_device(self.handle, k as c_int, &mut d)) };
+        d
+    }
+
     fn adopt(handle: *mut c_void) -> ShardedDevQueue {
         let mut n: c_int = 0;
         unsafe { check(cnt_sharded_dev_shards(handle, &mut n)) };
@@ -424,6 +490,20 @@ impl ShardedDevQueue {
             assert!(n_len[k] <= d_n[k].bytes);
         }
         unsafe { check(cnt_n_to_bits_sharded_dev_enqueue(self.handle, ins.as_ptr(), n_len.as_ptr(), outs.as_ptr(), caps.as_ptr(), 0)) };
+    }
+
+    /// Queue the VALIDATED encode of every shard: as `enqueue_n_to_bits`, and shard `k`'s op adds the number of its bytes
+    /// outside `ACGTUacgtu` to the `u64` in `d_invalid[k]` (>= 8 bytes on shard `k`'s device, zeroed by the caller).
+    pub fn enqueue_n_to_bits_checked(&mut self, d_n: &[&DeviceBuffer], n_len: &[usize], d_out: &[&DeviceBuffer], d_invalid: &[&DeviceBuffer]) {
+        assert!(d_n.len() == self.ndev && n_len.len() == self.ndev && d_out.len() == self.ndev && d_invalid.len() == self.ndev);
+        let ins: Vec<*const c_void> = d_n.iter().map(|b| b.ptr as *const c_void).collect();
+        let outs: Vec<*mut c_void> = d_out.iter().map(|b| b.ptr).collect();
+        let caps: Vec<usize> = d_out.iter().map(|b| b.bytes / 8).collect();
+        let counters: Vec<*mut c_void> = d_invalid.iter().map(|b| b.ptr).collect();
+        for k in 0..self.ndev {
+            assert!(n_len[k] <= d_n[k].bytes && d_invalid[k].bytes >= 8);
+        }
+        unsafe { check(cnt_n_to_bits_checked_sharded_dev_enqueue(self.handle, ins.as_ptr(), n_len.as_ptr(), outs.as_ptr(), caps.as_ptr(), 0, counters.as_ptr())) };
     }
 
     /// Queue the decode of every shard: `len[k]` nucleotides from `words[k]` words of `d_bits[k]` into `d_out[k]`.
@@ -559,6 +639,38 @@ mod tests {
         assert!(ms[0] > 0.0 && q.op_ms(5)[0] > 0.0);
         assert_eq!(d_back.to_vec::<u8>(n.len()), n);
         assert!(d_bits.to_vec::<u64>(n.len() / 32).iter().all(|w| *w == 0xD8D8D8D8D8D8D8D8));
+    }
+
+    #[test]
+    fn test_checked_encode_counts_what_byte_lut_zeroes() {
+        assert_eq!(n_to_bits_hip_checked(b"ATCGATCG"), (vec![0xD8D8u64], 0));
+        let (words, invalid) = n_to_bits_hip_checked(b"ATCGNNxx");
+        assert_eq!(invalid, 4);
+        assert_eq!(words, n_to_bits_hip(b"ATCGNNxx"));
+        assert_eq!(try_n_to_bits_hip(b"ATCGN"), Err(1));
+        assert_eq!(try_n_to_bits_hip(b"acgu"), Ok(n_to_bits_hip(b"ACGT")));
+        assert_eq!(n_to_bits2_hip_checked(b"ATCGN").1, 0);
+        assert_eq!(n_to_bits2_hip_checked(b"ATCGNx-").1, 2);
+        let d_n = DeviceBuffer::from_slice(&b"ATCGATCGATCGATCGATCGATCGATCGAT?G"[..]);
+        let d_bits = DeviceBuffer::new(8);
+        let d_bad = DeviceBuffer::from_slice(&[0u64][..]);
+        n_to_bits_hip_checked_dev(&d_n, 32, &d_bits, &d_bad);
+        device_sync();
+        assert_eq!(d_bad.to_vec::<u64>(1), vec![1u64]);
+    }
+
+    #[test]
+    fn test_queue_on_an_explicit_device_list() {
+        let n = b"ATCGATCGATCGATCGATCGATCGATCGATCN".repeat(64);
+        let mut q = ShardedDevQueue::on_devices(&[0, 0], false);
+        assert_eq!((q.shards(), q.device(0), q.device(1)), (2, 0, 0));
+        set_device(0);
+        let d_n = DeviceBuffer::from_slice(&n);
+        let (o0, o1) = (DeviceBuffer::new(n.len() / 4), DeviceBuffer::new(n.len() / 4));
+        let (c0, c1) = (DeviceBuffer::from_slice(&[0u64][..]), DeviceBuffer::from_slice(&[0u64][..]));
+        q.enqueue_n_to_bits_checked(&[&d_n, &d_n], &[n.len(), n.len() - 32], &[&o0, &o1], &[&c0, &c1]);
+        q.wait();
+        assert_eq!((c0.to_vec::<u64>(1)[0], c1.to_vec::<u64>(1)[0]), (64, 63));
     }
 
     #[test]

@@ -146,6 +146,41 @@ def test_argument_errors_before_any_device_work(L):
     assert L.cnt_fill_random_acgtn_dev(p(buf), 5, 27, 1, None) == _lib.CNT_ERANGE
 
 
+def test_round_6_entry_points_check_their_arguments_before_any_device_work(L):
+    """the validated encode's counter is never optional; an explicit device list is held to its contract BEFORE the device count is
+    asked (bogus lists are CNT_EINVAL on any box, an index past the visible devices CNT_ENODEV like everywhere else); a handle
+    that is not a live queue is CNT_EINVAL"""
+    from cute_nucleotides_amd import _lib
+
+    n = np.frombuffer(b"ACGT" * 16, dtype=np.uint8)
+    out = np.zeros(2, dtype=np.uint64)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    bad = ctypes.c_uint64(99)
+    assert L.cnt_n_to_bits_checked(p(n), 64, p(out), 1, 0, ctypes.byref(bad)) == _lib.CNT_ECAP and bad.value == 0
+    assert L.cnt_n_to_bits_checked(p(n), 64, p(out), 2, 0, None) == _lib.CNT_EINVAL
+    assert L.cnt_n_to_bits2_checked(p(n), 64, p(out), 2, 0, ctypes.byref(bad)) == _lib.CNT_ECAP
+    assert L.cnt_n_to_bits_checked(p(n), 64, p(out), 2, 0x80, ctypes.byref(bad)) == _lib.CNT_EINVAL
+    assert L.cnt_n_to_bits_checked_dev(p(n), 64, p(out), 2, 0, None, None) == _lib.CNT_EINVAL
+    assert L.cnt_round_trip_checked_dev(p(n), 64, p(out), 2, p(n), 0, None, None) == _lib.CNT_EINVAL
+    q = ctypes.c_void_p(1)
+    devs = lambda *v: (ctypes.c_int * len(v))(*v)
+    assert L.cnt_sharded_dev_open_on_devices(0, devs(0), 0, ctypes.byref(q)) == _lib.CNT_EINVAL and not q.value
+    assert L.cnt_sharded_dev_open_on_devices(2, None, 0, ctypes.byref(q)) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_open_on_devices(2, devs(0, -1), 0, ctypes.byref(q)) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_open_on_devices(65, devs(*([0] * 65)), 0, ctypes.byref(q)) == _lib.CNT_EINVAL
+    assert L.cnt_sharded_dev_open_on_devices(1, devs(0), 2, ctypes.byref(q)) == _lib.CNT_EINVAL  # unknown queue flag
+    assert L.cnt_sharded_dev_open_on_devices(1, devs(0), 0, None) == _lib.CNT_EINVAL
+    count = ctypes.c_int(-1)
+    assert L.cnt_device_count(ctypes.byref(count)) == _lib.CNT_OK
+    # a well-formed list naming a device that is not there: "device index out of range" (on this box: no device at all)
+    assert L.cnt_sharded_dev_open_on_devices(2, devs(0, count.value + 3), 0, ctypes.byref(q)) == _lib.CNT_ENODEV and not q.value
+    d = ctypes.c_int(7)
+    assert L.cnt_sharded_dev_device(ctypes.c_void_p(0xDEAD0), 0, ctypes.byref(d)) == _lib.CNT_EINVAL and d.value == 7
+    nt = ctypes.c_uint64(0)
+    assert L.cnt_chip_cache_nt(0, None) == _lib.CNT_EINVAL
+    assert L.cnt_chip_cache_nt(count.value + 1, ctypes.byref(nt)) == _lib.CNT_ENODEV
+
+
 def test_product_build_has_no_kernel_selection(L):
     """the product library contains the default kernels only and nothing that selects code at
     run time -- every cnt_set_tuning key is CNT_EINVAL, the variant tables hold one entry, the getters answer constants."""

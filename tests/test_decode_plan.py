@@ -27,18 +27,21 @@ def L():
     return lib
 
 
-def _plan(L, a_bits, a_out, n_len):
+SPX = 1 << 30  # cnt_chip_cache_nt of an SPX MI355X: 8 XCDs x 2^27 nt (32 MiB of packed words each)
+
+
+def _plan(L, a_bits, a_out, n_len, cache_nt=SPX):
     out = (ctypes.c_uint64 * 7)()
-    assert L.cnt_test_decode_plan(a_bits, a_out, n_len, out) == 0
+    assert L.cnt_test_decode_plan(a_bits, a_out, n_len, cache_nt, out) == 0
     return dict(zip(("head", "out_phase", "r", "sh", "q", "window", "tiles"), (int(x) for x in out)))
 
 
-def _check_common(p, a_bits, a_out, n_len, grain):
+def _check_common(p, a_bits, a_out, n_len, grain, cache_nt=SPX):
     """what every plan satisfies, whatever the size"""
     where = (hex(a_bits), hex(a_out), n_len, p)
     assert (a_out + p["head"]) % grain == 0 and p["out_phase"] == (a_out + p["head"]) % 4096, where
     assert p["sh"] == 2 * (p["head"] % 16) and p["q"] == ((a_bits + 4 * (p["head"] // 16)) % 128) // 4, where
-    assert p["window"] == (1 if (p["q"] or p["sh"]) and n_len > (1 << 30) else 0), where
+    assert p["window"] == (1 if (p["q"] or p["sh"]) and n_len > cache_nt else 0), where
     assert p["tiles"] == 0 or p["head"] + 4096 * p["tiles"] <= n_len, where  # no tiles: the generic kernel alone takes the call
     if p["window"]:
         if p["tiles"]:
@@ -100,8 +103,9 @@ def test_small_calls_peel_to_a_line_only(L):
                 peel = (128 - a_off % 128) % 128
                 assert p["head"] == peel and p["window"] == 0, (n_len, p_off, a_off, p)
     out = (ctypes.c_uint64 * 7)()
-    assert L.cnt_test_decode_plan(0x7F0000000004, 0, 1 << 20, out) != 0  # packed pointers are 8-byte aligned
-    assert L.cnt_test_decode_plan(0, 0, 1 << 20, None) != 0
+    assert L.cnt_test_decode_plan(0x7F0000000004, 0, 1 << 20, SPX, out) != 0  # packed pointers are 8-byte aligned
+    assert L.cnt_test_decode_plan(0, 0, 1 << 20, SPX, None) != 0
+    assert L.cnt_test_decode_plan(0, 0, 1 << 20, 0, out) != 0  # a device always has a share of the cache
 
 
 def test_short_and_ragged_lengths_never_plan_past_either_buffer(L):
@@ -111,3 +115,30 @@ def test_short_and_ragged_lengths_never_plan_past_either_buffer(L):
             for a_off in (0, 5, 16, 77, 2048, 4095):
                 grain = 4096 if n_len >= (1 << 20) else 128
                 _check_common(_plan(L, base_bits + p_off, base_out + a_off, n_len), base_bits + p_off, base_out + a_off, n_len, grain)
+
+
+def test_the_gate_follows_the_devices_share_of_the_infinity_cache(L):
+    """the one MI355X constant that did not come from the device -- `len > 2^30` = "256 MiB of Infinity
+    Cache" -- is now chip_info().cache_nt = XCDs x 2^27 nt, so a partitioned-mode device (1 / 2 / 4 XCDs, sharing the cache with
+    its siblings) takes the past-the-cache plan from 2^27 / 2^28 / 2^29 nt on instead of running the cached plan on buffers
+    that left its share long ago.  Walked for log2(XCDs) = 0..3 on both sides of each threshold."""
+    base_bits, base_out = 0x7F0000000000, 0x7E0000000000
+    for xs in range(4):
+        cache_nt = (1 << xs) << 27
+        for n_len, past in ((cache_nt, False), (cache_nt + 4096, True), (cache_nt // 2 + 77, False), (2 * cache_nt + 12345, True)):
+            placed = 0
+            for p_off in range(0, 4096, 136):
+                for a_off in (0, 5, 16, 2048, 4095):
+                    p = _plan(L, base_bits + p_off, base_out + a_off, n_len, cache_nt)
+                    _check_common(p, base_bits + p_off, base_out + a_off, n_len, 4096, cache_nt)
+                    peel = (4096 - a_off) % 4096
+                    if past:
+                        assert min(p["r"], 4096 - p["r"]) <= 512, (xs, n_len, p_off, a_off, p)  # the turns are placed ...
+                        placed += p["head"] != peel
+                    else:
+                        assert p["head"] == peel and not p["window"], (xs, n_len, p_off, a_off, p)  # ... or nothing is, inside the cache
+            assert (placed > 0) == past, (xs, n_len)
+    # the same call on the other side of the gate depending on the device: 2^29 + 1 nt is cached on SPX and streams on a CPX partition
+    a = _plan(L, base_bits + 264, base_out + 5, (1 << 29) + 1, 1 << 30)
+    b = _plan(L, base_bits + 264, base_out + 5, (1 << 29) + 1, 1 << 27)
+    assert not a["window"] and b["window"] and a["head"] != b["head"]

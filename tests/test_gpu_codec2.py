@@ -4,6 +4,8 @@ every edge case the reference tests or leaves undefined, and -- at BASELINE.json
 sizes -- size-independent properties (round trip, checksum of checksums).  Bit-exact: this
 is integer/byte work."""
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -39,7 +41,7 @@ def cn():
 def tuning(lab_build):
     from cute_nucleotides_amd import devutil
 
-    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "small_nt")}
+    saved = {k: devutil.get_tuning(k) for k in ("encode", "decode", "small_nt", "launch_tiles", "decode_cache_log2")}
     yield devutil
     for k, v in saved.items():
         devutil.set_tuning(k, v)
@@ -676,15 +678,24 @@ def test_fused_round_trip_config3_64gib(cn, oracle, torch_cuda, fullsize):
         assert torch.equal(v_back[lo : lo + (1 << 28)], v_in[lo : lo + (1 << 28)]), lo
 
 
-def test_decode_turn_rotation_at_every_kind_of_packed_offset(cn, oracle, torch_cuda):
-    """Round 5: for calls of >= 2^20 nt the decoder peels 0-3 further output pages so that its XCD turns
-    start near a page boundary of the PACKED buffer (device_tier.inc decode_turn_pages; tests/test_decode_plan.py walks the
-    arithmetic).  Here the product library decodes 2^20 + a ragged bit with the packed words at offsets that make every k
-    (0..3), with the stream and the shifted kernel (output phases 0 / 16 / 5 / 77), guards around the output -- a head of up to
-    16 383 letters rides in the edge items of the same launch -- bit-exact against bits_to_n_lut."""
-    from cute_nucleotides_amd import _lib
+@pytest.mark.parametrize("past_cache", [False, True])
+def test_decode_turn_rotation_at_every_kind_of_packed_offset(cn, oracle, torch_cuda, request, past_cache):
+    """Decodes of 2^20 + a ragged bit with the packed words at every kind of offset inside their page, output phases 0 / 16 / 5 /
+    77 / 4095, guards around the output, bit-exact against bits_to_n_lut.  As SHIPPED (past_cache = False, the product library)
+    a call of this size lies inside the Infinity Cache: the output is peeled to its 4-KiB page and the stream kernel (any dword
+    phase) or the shifted kernel (a bit phase) takes it -- NO turn placement, no window kernel: those start above
+    cnt_chip_cache_nt (2^30 nt on an SPX MI355X; round 5's docstring claimed them for >= 2^20).  past_cache = True
+    runs the same matrix on the lab build with the gate forced to 1 nt (tuning key decode_cache_log2 = 0): now the launcher peels
+    the 0-3 (+4) further pages that place the XCD turns (device_tier.inc decode_turn_pages) -- a head of up to 5 pages rides in
+    the edge items of the same launch -- and bits_to_n_window takes every packed stream off its lines or dwords."""
+    from cute_nucleotides_amd import _lib, devutil
 
-    assert not _lib.is_lab_build()
+    if past_cache:
+        request.getfixturevalue("lab_build")
+        devutil.set_tuning("decode_cache_log2", 0)
+        request.addfinalizer(lambda: devutil.set_tuning("decode_cache_log2", -1))
+    else:
+        assert not _lib.is_lab_build()
     torch = torch_cuda
     n_len = (1 << 20) + 4096 * 5 + 1234
     n = _rand_valid(n_len, 81)
@@ -709,6 +720,46 @@ def test_decode_turn_rotation_at_every_kind_of_packed_offset(cn, oracle, torch_c
         cn.bits_to_n_dev(d, m, out=obuf[3 : 3 + m])
         got = obuf.cpu().numpy()
         assert (got[:3] == 0x2A).all() and (got[3 + m :] == 0x2A).all() and np.array_equal(got[3 : 3 + m], want_back[:m]), p_off
+
+
+def test_window_decoder_at_every_packed_phase_with_the_gate_forced_open(cn, oracle, torch_cuda, tuning):
+    """bits_to_n_window is the shipped kernel for decodes past the Infinity Cache whose packed stream is off
+    its lines or dwords, and its only GPU coverage needed 4 GiB and reached q in {1, 2, 29, 30}, sh in {0, 2, 6, 22}.  Lab build,
+    gate forced to 1 nt (decode_cache_log2 = 0), at most 64 tiles per launch (the several-launch loop: edges in the last one
+    only): ALL 32 dword phases q x ALL 16 bit phases sh -- the worst case q = 31 with sh != 0 reaches the far end of the slab's
+    second row and the 144-byte slack behind the tile -- at 2^20 + a ragged bit, guard pages on both sides of the output,
+    against a decode of the same words on the grid (itself checked against bits_to_n_lut)."""
+    from cute_nucleotides_amd import _lib
+
+    torch = torch_cuda
+    tuning.set_tuning("decode_cache_log2", 0)
+    tuning.set_tuning("launch_tiles", 64)
+    L = _lib.lib()
+    try:
+        n_len = (1 << 20) + 4096 * 3 + 1234
+        bits = np.random.default_rng(83).integers(0, 2**64, (n_len + 31) // 32 + 4, dtype=np.uint64)
+        want = torch.from_numpy(oracle.bits_to_n_lut(bits, n_len)).cuda()
+        pbuf = torch.zeros(bits.size + 1024, dtype=torch.int64, device="cuda")
+        obuf = torch.empty(n_len + 4 * 4096, dtype=torch.uint8, device="cuda")
+        pb = ((-pbuf.data_ptr()) % 4096) // 8
+        ob = 4096 + (-obuf.data_ptr()) % 4096
+        seen = set()
+        plan = (ctypes.c_uint64 * 7)()
+        for p_off in (0, 8, 1016):  # packed bytes off the page: dword phases come from here AND from the output's peel
+            d = pbuf[pb + p_off // 8 : pb + p_off // 8 + bits.size]
+            d.copy_(torch.from_numpy(bits.view(np.int64)))
+            for a_off in range(0, 512) if p_off == 0 else range(3, 512, 37):
+                out = obuf[ob + a_off : ob + a_off + n_len]
+                assert L.cnt_test_decode_plan(d.data_ptr(), out.data_ptr(), n_len, 1, plan) == 0
+                seen.add((int(plan[4]), int(plan[3]) // 2, int(plan[5])))
+                obuf.fill_(0x2A)
+                cn.bits_to_n_dev(d, n_len, out=out)
+                assert torch.equal(out, want), (p_off, a_off, list(plan))
+                assert bool((obuf[: ob + a_off] == 0x2A).all()) and bool((obuf[ob + a_off + n_len :] == 0x2A).all()), (p_off, a_off)
+        assert {(q, sh) for q, sh, w in seen if w} >= {(q, sh) for q in range(32) for sh in range(16)} - {(0, 0)}  # every phase pair ran through the window kernel
+        assert (0, 0, 0) in seen  # ... and the grid itself through the stream kernel
+    finally:
+        tuning.set_tuning("decode_cache_log2", -1)
 
 
 def test_decode_past_the_infinity_cache_off_the_grid(cn, oracle, torch_cuda, fullsize):

@@ -117,13 +117,28 @@ def test_five_letter_codec_fuzz(oracle, small_nt, seed):
 
 @pytest.mark.parametrize("seed", range(2 * SEEDS))
 def test_large_decode_fuzz_over_packed_page_offsets(oracle, seed):
-    """Calls of >= 2^20 nt peel the output to a 4-KiB page and then 0-3 FURTHER pages so that the XCD turns start near a page
-    boundary of the packed buffer (round 5, device_tier.inc decode_turn_pages): random packed word offsets inside a page x
-    random output byte offsets x random lengths, the product library, guards around the output, against bits_to_n_lut."""
+    """Calls of >= 2^20 nt peel the output to a 4-KiB page; the 0-3 FURTHER pages that place the XCD turns on the packed buffer's
+    pages, and the window kernel, start above cnt_chip_cache_nt (2^30 nt on an SPX MI355X), so at these sizes the product runs
+    the page peel + stream / shifted kernels (odd seeds: the lab build with the gate forced to 1 nt, i.e. turn placement +
+    bits_to_n_window): random packed word offsets inside a page x random output byte offsets x random lengths, guards around the
+    output, against bits_to_n_lut."""
     import torch
 
     import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import _lib, devutil
 
+    if seed % 2:  # the past-the-cache plan at a size that fits any box: lab build, gate forced open
+        prev = _lib.use_lab_build(True)
+        devutil.set_tuning("decode_cache_log2", 0)
+    try:
+        _large_decode_fuzz(oracle, seed, torch, cn)
+    finally:
+        if seed % 2:
+            devutil.set_tuning("decode_cache_log2", -1)
+            _lib.use_lab_build(prev)
+
+
+def _large_decode_fuzz(oracle, seed, torch, cn):
     rng = np.random.default_rng(9000 + seed)
     cap_words = ((1 << 21) + 70000) // 32
     bits = rng.integers(0, 2**64, cap_words, dtype=np.uint64)
