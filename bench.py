@@ -149,7 +149,14 @@ def cpu_baseline(seconds, faithful_tables=True):
     parallel(enc, cores, 0.0)   # untimed: first-touch bits / out
     parallel(dec, cores, 0.0)
     q = max(seconds / 5.0, 0.5)
-    encN, decN = parallel(enc, cores, q), parallel(dec, cores, q)
+    # the all-core figure moved +-16 % between rounds on the same CPU model (150 ... 208 Gnt/s) -- one window
+    # of 256 threads is at the mercy of whatever else the host runs in it.  Three interleaved windows per direction, the MEDIAN on
+    # the line and all three beside it.
+    enc_runs, dec_runs = [], []
+    for _ in range(3):
+        enc_runs.append(parallel(enc, cores, q / 3.0))
+        dec_runs.append(parallel(dec, cores, q / 3.0))
+    encN, decN = sorted(enc_runs)[1], sorted(dec_runs)[1]
     enc1, dec1 = parallel(enc, 1, q), parallel(dec, 1, q)
     assert bytes(out[: 1 << 16]) == bytes(n[: 1 << 16])  # the timed decode really round-trips
     lut_nt = 1 << 24
@@ -169,6 +176,8 @@ def cpu_baseline(seconds, faithful_tables=True):
                   "n_to_bits_movemask + bits_to_n_shuffle ports (oracle/cnt_simd_port.c), output preallocated"
                   % (n_len >> 20, cores, seconds),
         "encode_gnts": round(encN, 3), "decode_gnts": round(decN, 3),
+        "all_core_windows": {"encode_gnts": [round(x, 1) for x in enc_runs], "decode_gnts": [round(x, 1) for x in dec_runs],
+                             "note": "three interleaved timing windows per direction; `encode_gnts` / `decode_gnts` / `value` use the medians"},
         "one_thread": {"encode_gnts": round(enc1, 3), "decode_gnts": round(dec1, 3), "value": round(both(enc1, dec1), 3),
                        "note": "one thread over the whole sample"},
         "scalar_lut_encode_gnts_1thread": round(lut_enc, 3), "cpu_model": model,

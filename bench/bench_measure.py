@@ -606,16 +606,32 @@ def one_device_env(parent, hip_index):
     """Environment entries that leave a child process with exactly ONE device: the parent's HIP device `hip_index`.  Hidden at
     the ROCr level (ROCR_VISIBLE_DEVICES), so that rocprofv3 itself -- which enumerates HSA agents, not HIP devices -- sets its
     counters up on that agent only; HIP then sees it as device 0.  HIP_VISIBLE_DEVICES indexes into the ROCr-visible set, so a
-    list the parent was given is resolved first; entries that are not plain indices (UUIDs) fall back to filtering in HIP."""
+    list the parent was given is resolved first; entries that are not plain indices (UUIDs) fall back to filtering in HIP.
+    HIP on ROCm honours CUDA_VISIBLE_DEVICES as well (torch launchers set it): when HIP_VISIBLE_DEVICES is unset it IS the index
+    list, and either way the child must not inherit it -- left in place it would be applied on top of the narrowed set and a
+    parent started with CUDA_VISIBLE_DEVICES=4,5 would profile physical GPU 0, somebody else's.  A value of None
+    means: remove the variable from the child's environment (apply_env does)."""
     hip = [x.strip() for x in parent.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip()]
+    if not hip:
+        hip = [x.strip() for x in parent.get("CUDA_VISIBLE_DEVICES", "").split(",") if x.strip()]
     rocr = [x.strip() for x in parent.get("ROCR_VISIBLE_DEVICES", "").split(",") if x.strip()]
     try:
         idx = int(hip[hip_index]) if hip else hip_index
         if rocr:
-            return {"ROCR_VISIBLE_DEVICES": rocr[idx], "HIP_VISIBLE_DEVICES": "0"}
-        return {"ROCR_VISIBLE_DEVICES": str(idx), "HIP_VISIBLE_DEVICES": "0"}
+            return {"ROCR_VISIBLE_DEVICES": rocr[idx], "HIP_VISIBLE_DEVICES": "0", "CUDA_VISIBLE_DEVICES": None}
+        return {"ROCR_VISIBLE_DEVICES": str(idx), "HIP_VISIBLE_DEVICES": "0", "CUDA_VISIBLE_DEVICES": None}
     except (ValueError, IndexError):
-        return {"HIP_VISIBLE_DEVICES": hip[hip_index] if hip_index < len(hip) else str(hip_index)}
+        return {"HIP_VISIBLE_DEVICES": hip[hip_index] if hip_index < len(hip) else str(hip_index), "CUDA_VISIBLE_DEVICES": None}
+
+
+def apply_env(env, updates):
+    """env.update(updates) where a value of None removes the variable"""
+    for k, v in updates.items():
+        if v is None:
+            env.pop(k, None)
+        else:
+            env[k] = v
+    return env
 
 
 def measure_traffic_live(log2_nt, timeout_s=90, child_device=None):
@@ -640,7 +656,7 @@ def measure_traffic_live(log2_nt, timeout_s=90, child_device=None):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CNT_BENCH_SHARE_GPU"):
         env.pop(k, None)  # the child is a plain one-device process, whatever launched the parent
     if child_device is not None:  # N > 1: the child -- rocprofv3's counter collection included -- sees rank 0's device only
-        env.update(one_device_env(os.environ, child_device))
+        apply_env(env, one_device_env(os.environ, child_device))
     try:
         csvs = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

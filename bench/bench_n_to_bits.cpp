@@ -92,6 +92,21 @@ int main(int argc, char** argv) {
             fprintf(stderr, "_into mismatch at 40000 nt\n");
             return 2;
         }
+        // the VALIDATED encode (round 6): the same call, and from the same pass the number of bytes BYTE_LUT would zero silently
+        {
+            uint64_t strays = 99;
+            bench_function("n_to_bits", "n_to_bits_hip_checked", 40000, [&] { g_sink += n_to_bits::n_to_bits_hip_checked(n.data(), n.size(), strays).back(); });
+            auto dirty = n;
+            dirty[0] = 'N';
+            dirty[20000] = '\n';
+            dirty[39999] = 0;
+            uint64_t strays3 = 0;
+            const auto w_dirty = n_to_bits::n_to_bits_hip_checked(dirty.data(), dirty.size(), strays3);
+            if (strays != 0 || strays3 != 3 || !(w_dirty == n_to_bits::n_to_bits_hip(dirty))) {
+                fprintf(stderr, "checked encode mismatch at 40000 nt (%llu, %llu)\n", (unsigned long long)strays, (unsigned long long)strays3);
+                return 2;
+            }
+        }
         // the same 40 000 nucleotides resident in HBM: one enqueue + one stream sync per call
         void *d_n = nullptr, *d_bits = nullptr, *d_back = nullptr;
         if (cnt_dev_alloc(&d_n, 40000) || cnt_dev_alloc(&d_bits, 1250 * 8) || cnt_dev_alloc(&d_back, 40000) ||

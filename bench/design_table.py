@@ -1,10 +1,26 @@
 #!/usr/bin/env python3
 """Print DESIGN.md's "round N in one table" from a bench.py JSON line, so the table is the file's numbers and
 nothing else:   python bench/design_table.py profiles/r02_bench_final.json"""
+import glob
 import json
+import os
+import re
 import sys
 
 j = json.load(open(sys.argv[1]))
+# The DRIVER's own measurement of the same command on its own (different) MI355X, taken at the end of a round: BENCH_rNN.json at
+# the repo root, written by the driver, never by the builder.  Its `parsed` block carries the contract keys only (value,
+# ms_per_step, roofline of the encode kernel), so the column has entries for those rows and a dash elsewhere.  The newest record
+# is used unless one is named: `design_table.py LINE.json [BENCH_rNN.json]`.
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+drv_path = sys.argv[2] if len(sys.argv) > 2 else (sorted(glob.glob(os.path.join(ROOT, "BENCH_r[0-9][0-9].json"))) or [None])[-1]
+drv = None
+if drv_path and os.path.exists(drv_path):
+    try:
+        drv = json.load(open(drv_path)).get("parsed") or None
+    except (OSError, ValueError):
+        drv = None
+drv_tag = re.sub(r"\.json$", "", os.path.basename(drv_path)) if drv else None
 c = j["ceilings"]["rank0"]
 tb = lambda gbs: "%.2f" % (gbs / 1000.0)
 fr = lambda gbs: "%.3f" % (gbs / 8000.0)
@@ -46,12 +62,27 @@ if "codec5" in j and "encode" in j["codec5"]:
     po = j["packed_ops"]
     rows.append(("packed-domain ops: hamming / complement / reverse complement / validate", " / ".join(tb(po[k]["achieved_GBs"]) for k in ("hamming", "complement", "reverse_complement", "validate")),
                  " / ".join("%.3f" % po[k]["frac"] for k in ("hamming", "complement", "reverse_complement", "validate")), "—"))
-print("| 2^34 nt, one MI355X | TB/s | of 8 TB/s | of its own no-arithmetic ceiling |")
-print("|---|---|---|---|")
-for row in rows:
-    print("| " + " | ".join(row) + " |")
-print()
-print("value = %.2f Tnt/s; traffic %s / %s bytes per launch (%s)" % (j["value"] / 1000.0, r["traffic"], d["traffic"], (r.get("traffic_source") or "")[:40]))
+    if "checked_encode" in po:
+        ce = po["checked_encode"]
+        rows.append(("validated encode `cnt_n_to_bits_checked_dev` (1.25 B/nt, one pass; validate + encode = 2.25 B/nt in two)", tb(ce["achieved_GBs"]), "**%.3f**" % ce["frac"],
+                     "×%.3f of the plain encode, ×%.3f of validate + encode (same run, interleaved)" % (ce["checked_over_plain"], ce["checked_over_two_pass"])))
+if drv and drv.get("roofline"):
+    dr = drv["roofline"]
+    extra = {2: "**%.3f** (%.3f ms)" % (dr["frac"], dr.get("avg_kernel_ms", 0)), 3: "**%.4f**" % (dr["frac"] / 1.25)}  # row index -> the driver's figure
+    print("| 2^34 nt, one MI355X | TB/s | of 8 TB/s | of its own no-arithmetic ceiling | driver's box (%s), of 8 TB/s |" % drv_tag)
+    print("|---|---|---|---|---|")
+    for i, row in enumerate(rows):
+        print("| " + " | ".join(row + (extra.get(i, "—"),)) + " |")
+    print()
+    print("value = %.2f Tnt/s here, %.3f Tnt/s on the driver's box (%s, %.4f ms per step); traffic %s / %s bytes per launch (%s)"
+          % (j["value"] / 1000.0, drv["value"] / 1000.0, drv_tag, drv["ms_per_step"], r["traffic"], d["traffic"], (r.get("traffic_source") or "")[:40]))
+else:
+    print("| 2^34 nt, one MI355X | TB/s | of 8 TB/s | of its own no-arithmetic ceiling |")
+    print("|---|---|---|---|")
+    for row in rows:
+        print("| " + " | ".join(row) + " |")
+    print()
+    print("value = %.2f Tnt/s; traffic %s / %s bytes per launch (%s)" % (j["value"] / 1000.0, r["traffic"], d["traffic"], (r.get("traffic_source") or "")[:40]))
 cb = j.get("cpu_baseline")
 if cb:
     print("cpu: all-core %.0f Gnt/s (enc %.0f, dec %.0f), one thread %.0f; cores %s" % (cb["value"], cb["encode_gnts"], cb["decode_gnts"], cb["one_thread"]["value"], cb["cores_detail"]))

@@ -39,7 +39,7 @@ def node_cpus():
     return out
 
 
-def child(sizes, reps):
+def child(sizes, reps, pin_after=None):
     import numpy as np
     import torch  # noqa: F401
 
@@ -50,6 +50,12 @@ def child(sizes, reps):
     rng = np.random.default_rng(1)
     p = lambda a: ctypes.c_void_p(a.ctypes.data)
     rows = {}
+    if pin_after:  # "the scheduler put the caller on that socket": the library meets an unrestricted thread first (its placement
+        # decisions -- staging ring, helper affinity -- are taken against the full mask), THEN the calling thread alone moves
+        w = np.frombuffer(b"ACGT" * (1 << 20), dtype=np.uint8)
+        wb = np.empty(w.size // 32, dtype=np.uint64)
+        assert L.cnt_n_to_bits(p(w), w.size, p(wb), wb.size) == 0
+        os.sched_setaffinity(0, {int(c) for c in pin_after.split(",")})  # the calling thread only
     for log2 in sizes:
         m = 1 << log2
         block = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, min(m, 1 << 20), dtype=np.uint8)]
@@ -98,8 +104,10 @@ def pcie_ceiling():
     return out
 
 
-def run_cell(env, cpus, sizes, reps):
+def run_cell(env, cpus, sizes, reps, pin_after=None):
     cmd = [sys.executable, os.path.abspath(__file__), "child", ",".join(map(str, sizes)), str(reps)]
+    if pin_after:
+        cmd.append(",".join(map(str, pin_after)))
     if cpus:
         cmd = ["taskset", "-c", ",".join(map(str, cpus))] + cmd
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
@@ -112,7 +120,7 @@ def run_cell(env, cpus, sizes, reps):
 def main():
     mode = sys.argv[1]
     if mode == "child":
-        return child([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]))
+        return child([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     import torch
 
     from cute_nucleotides_amd import devutil
@@ -136,6 +144,24 @@ def main():
             for where, cpus, env in cells:
                 out = run_cell(env, cpus, (26, 28, 30), 7)
                 print(json.dumps(dict(out, caller=where, env=env, round=rnd)), flush=True)
+    elif mode == "numa2":
+        # the far-socket caller WITHOUT a process-wide taskset (the BENCH_r05 situation: the scheduler's choice): only the calling
+        # thread sits on the far socket, so CNT_HOST_NUMA=1 can keep the copy helpers next to the staging ring
+        for rnd in range(3):
+            for where, cpus in (("near", near), ("far", far)):
+                for numa in ("1", "0"):
+                    for threads in ("4",):
+                        env = {"CNT_HOST_NUMA": numa, "CNT_HOST_COPY_THREADS": threads}
+                        out = run_cell(env, None, (26, 28, 30), 7, pin_after=cpus)
+                        print(json.dumps(dict(out, caller_thread=where, env=env, round=rnd)), flush=True)
+    elif mode == "history":
+        # does the size of the calls a process made BEFORE decide how fast its 1-GiB call runs?  (the staging ring grows on demand)
+        for rnd in range(3):
+            for sizes in ((30,), (26, 30), (22, 30), (22, 24, 30), (20, 22, 24, 26, 28, 30), (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)):
+                out = run_cell({}, near, sizes, 5)
+                if "rows" in out:
+                    out["rows"] = {"2^30": out["rows"]["2^30"]}
+                print(json.dumps(dict(out, sizes_in_order=list(sizes), round=rnd)), flush=True)
     elif mode == "pipeline":
         for rnd in range(2):
             for threads in ("4", "8"):

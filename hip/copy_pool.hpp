@@ -16,6 +16,9 @@
 
 #include <pthread.h>
 #include <sched.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #ifndef CNT_COPY_POOL_TEST_STALL
 #define CNT_COPY_POOL_TEST_STALL(k) ((void)0)
@@ -29,6 +32,43 @@
 // thread does the staging copies with it; CNT_HOST_COPY_THREADS (default 4, 1 = no helper threads at all) sizes the team
 // of warm copies, the caller included; copies into fresh pages use twice that team, so a calling thread owns up to
 // 2 x team - 1 helper threads (7 at the default), each spinning for up to 150 us after a copy before it sleeps.
+// memcpy with NON-TEMPORAL stores: the destination is not read by a CPU again soon -- the pinned staging ring, which the DMA
+// engine reads next, or an output larger than any cache -- so its lines need neither be fetched for ownership first (a third
+// of a plain copy's memory traffic) nor linger dirty in some core's L3, where the device's reads have to find them.
+// Lab-selectable (CNT_HOST_NT) until the A/B on the GPU box's host says which copies want it (profiles/r06_host_pipeline.md).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void copy_stream_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
+    size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
+    if (head > n) head = n;
+    memcpy(dst, src, head);
+    dst += head, src += head, n -= head;
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 96), d);
+    }
+    _mm_sfence();
+    memcpy(dst + i, src + i, n - i);
+}
+inline bool cpu_has_avx2() {
+    static const bool v = __builtin_cpu_supports("avx2");
+    return v;
+}
+#endif
+inline void copy_block(uint8_t* dst, const uint8_t* src, size_t n, bool stream_stores) {
+#if defined(__x86_64__)
+    if (stream_stores && n >= 4096 && cpu_has_avx2()) return copy_stream_avx2(dst, src, n);
+#endif
+    (void)stream_stores;
+    memcpy(dst, src, n);
+}
+
 class CopyPool {
    public:
     ~CopyPool() { stop(); }
@@ -41,19 +81,19 @@ class CopyPool {
     // nothing), and a helper that has run dry spins on the job generation for kSpinUs before it goes to sleep on the
     // condition variable -- inside a pipelined call it never sleeps, so a copy starts within a microsecond instead of the
     // 20-50 us of a condition-variable wake-up (which made 8 threads SLOWER than 4 in the first version of this pool).
-    void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false) {
+    void copy(uint8_t* dst, const uint8_t* src, size_t bytes, bool fresh_pages = false, bool stream_stores = false) {
         // small copies never wake a sleeping team, and an ISOLATED one never starts it: below kMinPar always the caller's
         // memcpy; up to kSmallCopy (the band the zero-copy small calls fall into) a team that is already running is joined,
         // and one that is not is started only by the SECOND such copy within kStreakUs -- a loop of mid-size calls, where the
         // spinning helpers take 16 % off a 2^20-nt decode (profiles/r04_host_small_copies.md) -- so that a lone mid-size
         // call does not pay for creating up to seven threads that then spin for 150 us each
         if (bytes < kMinPar) {
-            memcpy(dst, src, bytes);
+            copy_block(dst, src, bytes, stream_stores);
             return;
         }
         if (bytes <= kSmallCopy && !started_) {
             if (std::chrono::steady_clock::now() - last_mid_copy_ >= std::chrono::microseconds(kStreakUs)) {
-                memcpy(dst, src, bytes);
+                copy_block(dst, src, bytes, stream_stores);
                 last_mid_copy_ = std::chrono::steady_clock::now();  // the END of this copy: the streak is the gap between calls
                 return;
             }
@@ -61,7 +101,7 @@ class CopyPool {
         const int all = threads();
         const int T = fresh_pages ? all : std::max(1, (all + 1) / 2);  // warm copies use the configured team, fresh ones twice that
         if (T <= 1) {
-            memcpy(dst, src, bytes);
+            copy_block(dst, src, bytes, stream_stores);
             return;
         }
         const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
@@ -89,6 +129,7 @@ class CopyPool {
         job_blk_.store(blk, std::memory_order_relaxed);
         job_nblocks_.store(nblocks, std::memory_order_relaxed);
         job_team_.store(T, std::memory_order_relaxed);
+        job_stream_.store(stream_stores, std::memory_order_relaxed);
         gen_.store(g, std::memory_order_seq_cst);
         // helpers that are still spinning (the previous copy was < 150 us ago) join at once; sleeping ones are woken only for
         // copies worth a 20-50 us wake-up -- a 1-MiB copy of an isolated small call is the caller's alone, as it always was
@@ -96,7 +137,7 @@ class CopyPool {
             std::lock_guard<std::mutex> lk(m_);
             cv_work_.notify_all();
         }
-        work(g, dst, src, bytes, blk, nblocks);
+        work(g, dst, src, bytes, blk, nblocks, stream_stores);
         // blocks still in other hands: normally < 30 us; a helper that was preempted while holding one can take a scheduler
         // quantum, so after a short spin the caller yields its CPU instead of burning it
         for (unsigned spins = 1; done_.load(std::memory_order_acquire) < nblocks; ++spins) {
@@ -167,7 +208,7 @@ class CopyPool {
     }
     // take blocks of job `g` until none is left; the generation in the counter's high half keeps a straggler of an
     // older job from ever taking (and losing) a block of this one
-    void work(uint64_t g, uint8_t* dst, const uint8_t* src, size_t bytes, size_t blk, uint64_t nblocks) {
+    void work(uint64_t g, uint8_t* dst, const uint8_t* src, size_t bytes, size_t blk, uint64_t nblocks, bool stream_stores) {
         const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
         for (;;) {
             uint64_t cur = next_.load(std::memory_order_acquire);
@@ -175,7 +216,7 @@ class CopyPool {
             if (!next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
             const size_t b = (size_t)(cur & 0xFFFFFFFFull);
             const size_t lo = b ? b * blk - skew : 0, hi = std::min(bytes, (b + 1) * blk - skew);
-            memcpy(dst + lo, src + lo, hi - lo);
+            copy_block(dst + lo, src + lo, hi - lo, stream_stores);
             done_.fetch_add(1, std::memory_order_release);
         }
     }
@@ -208,9 +249,10 @@ class CopyPool {
             const size_t blk = job_blk_.load(std::memory_order_relaxed);
             const uint64_t nblocks = job_nblocks_.load(std::memory_order_relaxed);
             const int team = job_team_.load(std::memory_order_relaxed);
+            const bool stream_stores = job_stream_.load(std::memory_order_relaxed);
             std::atomic_thread_fence(std::memory_order_acquire);
             if (k >= team) continue;
-            work(g, dst, src, bytes, blk, nblocks);
+            work(g, dst, src, bytes, blk, nblocks, stream_stores);
         }
     }
     std::mutex m_;
@@ -222,6 +264,7 @@ class CopyPool {
     std::atomic<size_t> job_bytes_{0}, job_blk_{0};
     std::atomic<uint64_t> job_nblocks_{0};
     std::atomic<int> job_team_{0}, sleepers_{0};
+    std::atomic<bool> job_stream_{false};
     std::atomic<bool> stop_{false};
     int n_threads_ = 1, team_ = 1, limit_ = 0;
     bool started_ = false, have_cpus_ = false;

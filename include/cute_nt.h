@@ -356,7 +356,9 @@ int cnt_count_mismatch_dev(const void *d_a, const void *d_b, size_t nbytes, void
  *   maps assume (-1 = ask the device, the default; get returns the value in effect) -- the maps are bijections for every
  *   value, only speed depends on it.  "launch_tiles": most tiles one kernel launch may take (a multiple of 64; 0 = the
  *   hardware's limit of 2^31-1 threads, the default) -- test support: lets a few MiB walk the several-launch loops that
- *   otherwise start at 2^36 nt.
+ *   otherwise start at 2^36 nt.  "decode_cache_log2": log2 of the size beyond which cnt_bits_to_n_dev plans for a packed
+ *   stream that has left the Infinity Cache (-1 = cnt_chip_cache_nt of the device, the default; 0 = every call) -- test
+ *   support: lets 2^20-nt calls walk turn placement and bits_to_n_window at every packed phase.
  * cnt_tuning_name returns the variant's description (NULL when out of range).  CNT_EINVAL for unknown keys / values. */
 int cnt_set_tuning(const char *key, int value);
 int cnt_get_tuning(const char *key, int *value);

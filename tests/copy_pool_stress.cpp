@@ -63,10 +63,11 @@ static int run_thread(unsigned seed, int copies, size_t max_bytes) {
         size_t bytes = kind == 0 ? rng() % 4096 : kind == 1 ? ((size_t)512 << 10) + rng() % 3 - 1 : rng() % max_bytes;
         const size_t so = rng() % 4096, doff = 4096 + rng() % 4096;
         const bool fresh = (rng() & 3) == 0;
+        const bool stream = (rng() & 1) == 0;  // non-temporal stores (round 6): any alignment, any length, guards intact
         memset(dst.data() + doff - 64, 0xA5, 64);
         memset(dst.data() + doff + bytes, 0x5A, 64);
         memset(dst.data() + doff, 0, bytes);
-        pool.copy(dst.data() + doff, src.data() + so, bytes, fresh);
+        pool.copy(dst.data() + doff, src.data() + so, bytes, fresh, stream);
         if (memcmp(dst.data() + doff, src.data() + so, bytes) != 0) ++bad;
         for (int g = 0; g < 64; ++g)
             if (dst[doff - 64 + g] != 0xA5 || dst[doff + bytes + g] != 0x5A) ++bad;

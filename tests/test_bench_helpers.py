@@ -191,9 +191,17 @@ def test_the_pmc_child_of_an_n_gpu_line_sees_one_device():
     that the profiler's own agent enumeration is restricted too; visibility lists the parent was launched under are resolved"""
     import bench_measure as bm
 
-    assert bm.one_device_env({}, 0) == {"ROCR_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0"}
-    assert bm.one_device_env({}, 5) == {"ROCR_VISIBLE_DEVICES": "5", "HIP_VISIBLE_DEVICES": "0"}
-    assert bm.one_device_env({"HIP_VISIBLE_DEVICES": "4,5,6,7"}, 2) == {"ROCR_VISIBLE_DEVICES": "6", "HIP_VISIBLE_DEVICES": "0"}
-    assert bm.one_device_env({"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1,0"}, 0) == {"ROCR_VISIBLE_DEVICES": "3", "HIP_VISIBLE_DEVICES": "0"}
-    assert bm.one_device_env({"ROCR_VISIBLE_DEVICES": "GPU-abc,GPU-def"}, 1) == {"ROCR_VISIBLE_DEVICES": "GPU-def", "HIP_VISIBLE_DEVICES": "0"}
-    assert bm.one_device_env({"HIP_VISIBLE_DEVICES": "GPU-abc,GPU-def"}, 1) == {"HIP_VISIBLE_DEVICES": "GPU-def"}  # UUIDs: filter in HIP
+    gone = {"CUDA_VISIBLE_DEVICES": None}  # never inherited: it would be applied on top of the narrowed set
+    assert bm.one_device_env({}, 0) == dict(gone, ROCR_VISIBLE_DEVICES="0", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({}, 5) == dict(gone, ROCR_VISIBLE_DEVICES="5", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({"HIP_VISIBLE_DEVICES": "4,5,6,7"}, 2) == dict(gone, ROCR_VISIBLE_DEVICES="6", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1,0"}, 0) == dict(gone, ROCR_VISIBLE_DEVICES="3", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({"ROCR_VISIBLE_DEVICES": "GPU-abc,GPU-def"}, 1) == dict(gone, ROCR_VISIBLE_DEVICES="GPU-def", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({"HIP_VISIBLE_DEVICES": "GPU-abc,GPU-def"}, 1) == dict(gone, HIP_VISIBLE_DEVICES="GPU-def")  # UUIDs: filter in HIP
+    # ADVICE r05: HIP on ROCm honours CUDA_VISIBLE_DEVICES too -- with HIP_VISIBLE_DEVICES unset it is the index list (rank 0 of a
+    # parent started with CUDA_VISIBLE_DEVICES=4,5 is physical GPU 4, not 0), HIP_VISIBLE_DEVICES wins when both are set
+    assert bm.one_device_env({"CUDA_VISIBLE_DEVICES": "4,5"}, 0) == dict(gone, ROCR_VISIBLE_DEVICES="4", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({"CUDA_VISIBLE_DEVICES": "4,5", "ROCR_VISIBLE_DEVICES": "0,1,2,3,7,6"}, 1) == dict(gone, ROCR_VISIBLE_DEVICES="6", HIP_VISIBLE_DEVICES="0")
+    assert bm.one_device_env({"CUDA_VISIBLE_DEVICES": "4,5", "HIP_VISIBLE_DEVICES": "2"}, 0) == dict(gone, ROCR_VISIBLE_DEVICES="2", HIP_VISIBLE_DEVICES="0")
+    env = bm.apply_env({"CUDA_VISIBLE_DEVICES": "4,5", "PATH": "/bin"}, bm.one_device_env({"CUDA_VISIBLE_DEVICES": "4,5"}, 1))
+    assert env == {"PATH": "/bin", "ROCR_VISIBLE_DEVICES": "5", "HIP_VISIBLE_DEVICES": "0"}

@@ -218,10 +218,11 @@ def test_checked_calls_walk_the_several_launch_loop(cn, oracle, torch_cuda, tuni
     n = _mixed(n_len, 4)
     d = torch.from_numpy(n).cuda()
     for view in (d, torch.cat([torch.zeros(3, dtype=torch.uint8, device="cuda"), d])[3:]):
-        w, acc = cn.n_to_bits_checked_dev(view)
+        w, acc = cn.n_to_bits_checked_dev(view, tail_lut=True)  # the SIMD encoders to the letter: what the oracle's bit-extract port computes
         assert np.array_equal(w.cpu().numpy().view(np.uint64), oracle.n_to_bits_bitextract(n)) and int(acc.item()) == oracle.validate(n)
-        b, back, acc2 = cn.round_trip_checked_dev(view)
+        b, back, acc2 = cn.round_trip_checked_dev(view, tail_lut=True)
         assert torch.equal(b, w) and int(acc2.item()) == oracle.validate(n)
+        assert torch.equal(cn.n_to_bits_checked_dev(view)[0], cn.n_to_bits_dev(view))
     n5 = _mixed(3456 * 64 * 2 + 3456 * 3 + 5, 6, five=True)
     w5, acc5 = cn.n_to_bits2_checked_dev(torch.from_numpy(n5).cuda())
     assert torch.equal(w5, cn.n_to_bits2_dev(torch.from_numpy(n5).cuda())) and int(acc5.item()) == oracle.validate(n5, allow_n=True)
@@ -244,8 +245,8 @@ def test_checked_calls_are_one_launch_and_graph_capturable(cn, oracle, torch_cud
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         acc.zero_()
-        cn.n_to_bits_checked_dev(d_in, out=d_pk, acc=acc[0:1])
-        cn.round_trip_checked_dev(d_in, out_bits=d_pk2, out_n=d_back, acc=acc[1:2])
+        cn.n_to_bits_checked_dev(d_in, out=d_pk, acc=acc[0:1], tail_lut=True)
+        cn.round_trip_checked_dev(d_in, out_bits=d_pk2, out_n=d_back, acc=acc[1:2], tail_lut=True)
     for seed in (1, 2, 3):
         n = _mixed(n_len, seed)
         d_in.copy_(torch.from_numpy(n))
@@ -312,9 +313,9 @@ def test_sharded_queue_checked_forms_on_an_explicit_device_list(cn, oracle, torc
     bad2 = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in lens]
     with sharding.DevQueue(devices=[0, 0, 0], timed=True) as q:
         assert q.ndev == 3 and q.devices == [0, 0, 0]
-        q.n_to_bits(shards, outs, invalid=bad)
+        q.n_to_bits(shards, outs, invalid=bad, tail_lut=True)
         q.round_trip(shards, outs2, backs, invalid=bad2, strict_lut=True)
-        q.n_to_bits(shards, outs, invalid=bad)  # adds again
+        q.n_to_bits(shards, outs, invalid=bad, tail_lut=True)  # adds again
         ms = q.wait()
         assert ms[0] > 0 and ms[2] > 0
     for k, n in enumerate(ns):
