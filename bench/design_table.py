@@ -14,6 +14,10 @@ j = json.load(open(sys.argv[1]))
 # is used unless one is named: `design_table.py LINE.json [BENCH_rNN.json]`.
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 drv_path = sys.argv[2] if len(sys.argv) > 2 else (sorted(glob.glob(os.path.join(ROOT, "BENCH_r[0-9][0-9].json"))) or [None])[-1]
+if drv_path == "none":  # the tables of rounds 2-5 (profiles/HISTORY.md) were printed without the column
+    drv_path = None
+elif drv_path and not os.path.isabs(drv_path) and not os.path.exists(drv_path):
+    drv_path = os.path.join(ROOT, drv_path)
 drv = None
 if drv_path and os.path.exists(drv_path):
     try:

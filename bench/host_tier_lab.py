@@ -64,7 +64,11 @@ def child(sizes, reps, pin_after=None):
         back = np.empty(m, dtype=np.uint8)
         row = {}
         for name, fn in (("enc", lambda: L.cnt_n_to_bits(p(n), m, p(bits), m // 32)), ("dec", lambda: L.cnt_bits_to_n(p(bits), m // 32, m, p(back)))):
-            assert fn() == 0 and fn() == 0
+            t0 = time.perf_counter()
+            assert fn() == 0
+            if not rows and name == "enc":
+                row["first_call_of_the_process_us"] = round((time.perf_counter() - t0) * 1e6, 1)  # streams, staging ring, engine warm-up
+            assert fn() == 0
             ts = []
             k = reps if log2 >= 28 else reps * 3
             for _ in range(k):
@@ -156,16 +160,21 @@ def main():
                         print(json.dumps(dict(out, caller_thread=where, env=env, round=rnd)), flush=True)
     elif mode == "history":
         # does the size of the calls a process made BEFORE decide how fast its 1-GiB call runs?  (the staging ring grows on demand)
+        for rnd in range(2):
+            for warm, pre in (("0", "0"), ("1", "1")):
+                for sizes in ((30,), (22, 30), (20, 22, 30), (21, 30)):
+                    out = run_cell({"CNT_HOST_PREALLOC": pre, "CNT_HOST_WARM": warm}, near, sizes, 5)
+                    print(json.dumps(dict(out, sizes_in_order=list(sizes), prealloc=pre, warm=warm, round=rnd)), flush=True)
+    elif mode == "nt":
+        # non-temporal stores for the staging copies (bit 0) / the copy-outs (bit 1), against plain memcpy; 1 GiB and 64 MiB
         for rnd in range(3):
-            for sizes in ((30,), (26, 30), (22, 30), (22, 24, 30), (20, 22, 24, 26, 28, 30), (12, 14, 16, 18, 20, 22, 24, 26, 28, 30)):
-                out = run_cell({}, near, sizes, 5)
-                if "rows" in out:
-                    out["rows"] = {"2^30": out["rows"]["2^30"]}
-                print(json.dumps(dict(out, sizes_in_order=list(sizes), round=rnd)), flush=True)
+            for nt in ("0", "1", "3", "2"):
+                out = run_cell({"CNT_HOST_NT": nt}, near, (30, 26), 5)
+                print(json.dumps(dict(out, env={"CNT_HOST_NT": nt}, round=rnd)), flush=True)
     elif mode == "pipeline":
         for rnd in range(2):
             for threads in ("4", "8"):
-                for chunk in ("16", "8", "4"):
+                for chunk in ("16", "8"):
                     for pieces in ("4", "8", "16"):
                         env = {"CNT_HOST_COPY_THREADS": threads, "CNT_HOST_CHUNK_MI": chunk, "CNT_HOST_PIECES": pieces}
                         out = run_cell(env, near, (22, 24, 26, 27, 28, 30), 7)

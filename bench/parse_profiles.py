@@ -42,7 +42,7 @@ def traffic_summary(fetch_csv, write_csv, n, tag=""):
     k_read, k_write = pick(fetch, "k_read<"), pick(write, "k_write<")
     f_cal = n / (fetch[k_read][0] * 1024.0)   # true bytes per reported FETCH_SIZE byte
     w_cal = n / (write[k_write][0] * 1024.0)
-    enc, dec = pick(fetch, "n_to_bits_"), pick(fetch, "bits_to_n_")
+    enc, dec = pick(fetch, "n_to_bits_stream<"), pick(fetch, "bits_to_n_")  # ("n_to_bits_stream_checked<" is its own row below)
 
     def traffic(name, algorithmic=None):
         algorithmic = 1.25 * n if algorithmic is None else algorithmic
@@ -63,8 +63,8 @@ def traffic_summary(fetch_csv, write_csv, n, tag=""):
     }
     n5 = 27 * (1 << 28)
     for key, needle, alg in (("encode_5letter", "n_to_bits2_wave", n5 * (1 + 8 / 27)), ("decode_5letter", "bits_to_n2_wave", n5 * (1 + 8 / 27)),
-                             ("hamming", "hamming_tiles", 0.5 * n), ("complement", "complement_tiles", 0.5 * n),
-                             ("validate", "validate_tiles", 1.0 * n)):
+                             ("hamming", "hamming_persist", 0.5 * n), ("complement", "complement_tiles", 0.5 * n),
+                             ("validate", "validate_persist", 1.0 * n), ("checked_encode", "n_to_bits_stream_checked<", 1.25 * n)):
         hits = [k for k in fetch if needle in k]
         if len(hits) == 1:
             summary[key] = traffic(hits[0], alg)

@@ -55,9 +55,12 @@ if n5 <= n:
 devutil.fill_random_acgt(d_in, 0x5EED)
 cn.n_to_bits_dev(d_in, out=d_packed)
 other = torch.empty_like(d_packed)
+acc = torch.zeros(1, dtype=torch.int64, device="cuda")
 for _ in range(a.reps):
     po.complement_dev(d_packed, n, out=other)
     po.hamming_dev(d_packed, other, n)
     po.validate_dev(d_in)
+    cn.n_to_bits_checked_dev(d_in, out=d_packed, acc=acc)  # the validated encode: its traffic must be the plain encode's (1.25 B/nt)
+assert int(acc.item()) == 0
 torch.cuda.synchronize()
 print("pmc workload ok: n = 2^%d, reps = %d" % (a.log2_nt, a.reps))

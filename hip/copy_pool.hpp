@@ -152,17 +152,28 @@ class CopyPool {
         limit_ = n;
         if (started_) stop();
     }
-    // Where the HELPERS run (the caller is never moved): the CPUs of the NUMA node the GPU hangs off, so that the staging
-    // copies' far end -- the pinned ring, which lives there -- is local to most of the team (host tier, CNT_HOST_NUMA); nullptr =
-    // wherever the caller's own mask lets them.  Takes effect at the next copy() (a running team is stopped and restarts).
-    void set_cpus(const cpu_set_t* cpus) {
-        const bool want = cpus != nullptr;
-        if (want == have_cpus_ && (!want || CPU_EQUAL(cpus, &cpus_))) return;
-        have_cpus_ = want;
-        if (want) cpus_ = *cpus;
+    // Where the HELPERS run (the caller is never moved).  `domains` = sets of CPUs that share a last-level cache, i.e. on an EPYC
+    // one CCD each -- and every CCD reaches memory through a link of its own: four copying threads inside ONE CCD move 59 GB/s
+    // together, one thread in each of four CCDs 100 GB/s, eight 152 GB/s (bench/copy_placement_lab.cpp on the GPU box's host,
+    // profiles/r06_host_placement.md).  Left to the scheduler the team landed anywhere in between, per process: the 1-GiB
+    // host-slice calls ran in 22.1 ms or in 25.9 ms.  Helper k is pinned to domain (first + k - 1) mod n: distinct domains as long
+    // as there are enough, starting behind the caller's own.  Empty = wherever the caller's mask lets them (CNT_HOST_NUMA=0).
+    // Takes effect at the next copy() (a running team is stopped and restarts).
+    void set_domains(const std::vector<cpu_set_t>& domains, size_t first) {
+        bool same = domains.size() == domains_.size() && (domains.empty() || first == first_);
+        for (size_t i = 0; same && i < domains.size(); ++i) same = CPU_EQUAL(&domains[i], &domains_[i]) != 0;
+        if (same) return;
+        domains_ = domains;
+        first_ = first;
         if (started_) stop();
     }
-    int pinned_cpus() const { return have_cpus_ ? CPU_COUNT(&cpus_) : 0; }
+    int pinned_cpus() const {  // CPUs the helpers may run on, all domains together (0 = not pinned)
+        cpu_set_t all;
+        CPU_ZERO(&all);
+        for (const cpu_set_t& d : domains_) CPU_OR(&all, &all, &d);
+        return CPU_COUNT(&all);
+    }
+    int domains() const { return (int)domains_.size(); }
     // the warm-copy team = what CNT_HOST_COPY_THREADS / the sharded budget count (the caller is one of them); threads that
     // EXIST besides the caller: spawned() -- up to 2 x team - 1, the second half only works on copies into fresh pages
     int size() const { return started_ ? team_ : 0; }
@@ -221,7 +232,10 @@ class CopyPool {
         }
     }
     void run(int k, uint64_t seen) {
-        if (have_cpus_) (void)pthread_setaffinity_np(pthread_self(), sizeof cpus_, &cpus_);  // set before the team starts, never changed under it
+        if (!domains_.empty()) {  // set before the team starts, never changed under it
+            const cpu_set_t& mine = domains_[(first_ + (size_t)k - 1) % domains_.size()];
+            (void)pthread_setaffinity_np(pthread_self(), sizeof mine, &mine);
+        }
         for (;;) {
             // wait for a new generation: spin first (the next copy of a pipelined call is microseconds away), then sleep
             const auto t0 = std::chrono::steady_clock::now();
@@ -267,7 +281,8 @@ class CopyPool {
     std::atomic<bool> job_stream_{false};
     std::atomic<bool> stop_{false};
     int n_threads_ = 1, team_ = 1, limit_ = 0;
-    bool started_ = false, have_cpus_ = false;
-    cpu_set_t cpus_;
+    bool started_ = false;
+    std::vector<cpu_set_t> domains_;
+    size_t first_ = 0;
     std::chrono::steady_clock::time_point last_mid_copy_{};  // when the calling thread's previous lone mid-size copy ended (a pool has one caller)
 };

@@ -390,8 +390,18 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                default).  The helpers spin for up to 150 us after a copy before they go to sleep, i.e.
  *                                for the length of a pipelined call
  *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 3, 2..4).  Footprint per calling thread (and
- *                                per sharded-tier worker) and device: slots x (16 + 16) MiB of pinned host memory and as much
- *                                device scratch, grown on demand (96 + 96 MiB at the default), released by cnt_shutdown()
+ *                                per sharded-tier worker) and device: slots x (8 + 8) MiB of pinned host memory and as much
+ *                                device scratch (48 + 48 MiB at the default), allocated whole by the thread's first call of
+ *                                more than 2^20 nt, released by cnt_shutdown()
+ *   CNT_HOST_WARM=0              do NOT let the ring's streams make their first copies at allocation time.  The default does:
+ *                                the runtime binds a stream to a copy engine when it first copies and takes the engines idle at
+ *                                that moment, so a thread whose first pipelined call was a small one (short copies that never
+ *                                overlapped) kept ALL its streams on one engine and ran every later call 15-20 % slower
+ *                                (25.9 instead of 22.1 ms per GiB, deterministically).  CNT_HOST_PREALLOC=0: grow the ring with
+ *                                the calls instead of allocating it whole (the warm-up then copies what exists)
+ *   CNT_HOST_CHUNK_MI, CNT_HOST_PIECES, CNT_HOST_NT   A/B knobs of the pipeline (chunk size in Mi nt, default 8; minimum
+ *                                pieces of a mid-size call, default 4; non-temporal stores for the staging copies / copy-outs,
+ *                                default off: measured slower at 1 GiB) -- bench/host_tier_lab.py
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)

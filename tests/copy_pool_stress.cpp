@@ -74,6 +74,20 @@ static int run_thread(unsigned seed, int copies, size_t max_bytes) {
         if (i % 97 == 0) std::this_thread::sleep_for(std::chrono::microseconds(400));  // longer than the helpers spin
         if (i % 211 == 0) pool.stop();                                                   // restarts at the next copy
         if (i % 389 == 0) pool.set_limit(1 + (int)(rng() % 4));
+        if (i % 173 == 0) {  // round 6: helpers pinned one per cache domain -- here: one per allowed CPU, or not at all; the team restarts
+            std::vector<cpu_set_t> doms;
+            cpu_set_t allowed;
+            CPU_ZERO(&allowed);
+            if ((rng() & 1) && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+                for (int c = 0; c < CPU_SETSIZE && doms.size() < 5; ++c)
+                    if (CPU_ISSET(c, &allowed)) {
+                        cpu_set_t one;
+                        CPU_ZERO(&one);
+                        CPU_SET(c, &one);
+                        doms.push_back(one);
+                    }
+            pool.set_domains(doms, (size_t)(rng() % 7));
+        }
     }
     return bad;
 }

@@ -465,17 +465,37 @@ def test_queue_runs_behind_the_callers_streams_without_any_host_sync(L, oracle, 
         producers[0].synchronize()
         assert int(d_out[0][0].item()) == 65
     elif ndev == 1:
-        # control: the same pipeline WITHOUT cnt_sharded_dev_wait_event encodes the buffer before the producer wrote it
-        d_in[0].zero_()
-        torch.cuda.synchronize()
-        with sharding.DevQueue(1) as q2:
-            produce(0)
-            q2.n_to_bits(d_in, d_pk)
-            raced = not filled[0].query()
-            q2.wait()
-        torch.cuda.synchronize()
-        if raced:
-            assert not np.array_equal(d_pk[0].cpu().numpy().view(np.uint64), oracle.n_to_bits_lut(oracle.fill_random_acgt(sizes[0], seeds[0])))
+        # control: the same pipeline WITHOUT cnt_sharded_dev_wait_event encodes the buffer before the producer wrote it.  Two HIP
+        # streams that the runtime maps onto the same hardware queue run in order whatever the program says (round 6: the
+        # control met exactly that once the process had created a different number of streams before it), so the control counts
+        # only when the encode is SEEN to finish while the producer is still asleep -- and one of a few fresh queues must get there.
+        want0 = oracle.n_to_bits_lut(oracle.fill_random_acgt(sizes[0], seeds[0]))
+        raced = 0
+        shifters = []  # streams kept alive so that every attempt's fresh queue lands on another hardware queue than the last one's
+        for attempt in range(8):
+            d_in[0].zero_()
+            d_pk[0].fill_(-1)
+            shifters.append(torch.cuda.Stream(device=dev))
+            torch.cuda.synchronize()
+            with sharding.DevQueue(1) as q2:
+                enc_done = torch.cuda.Event()
+                enc_done.record(consumers[0])  # torch creates the HIP event on first record; the queue re-records it
+                torch.cuda.synchronize()
+                produce(0)
+                q2.n_to_bits(d_in, d_pk)
+                q2.record_event(0, enc_done)
+                overtook = False
+                while not filled[0].query():
+                    if enc_done.query():
+                        overtook = True
+                        break
+                q2.wait()
+            torch.cuda.synchronize()
+            if overtook:
+                raced += 1
+                assert not np.array_equal(d_pk[0].cpu().numpy().view(np.uint64), want0), attempt  # it packed the buffer of zeros
+                break
+        assert raced, "none of 8 fresh queues ran ahead of the sleeping producer: the control never tested anything"
     assert torch.cuda.current_device() == 0
 
 
