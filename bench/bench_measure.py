@@ -295,6 +295,20 @@ def measure_packed_ops(torch, seed, log2_nt, reps=4, queue=5):
     cn.n_to_bits_checked_dev(d, out=out, acc=acc)
     ok_checked = ok_checked and int(acc.item()) == spots.numel()
     d[spots] = keep
+    # the other end of the scale: EVERY 2-KiB tile holds a stray (a line feed after every 60 letters, a FASTA file fed in whole)
+    # -- every wave recounts its registers exactly and issues one atomic on the single counter -- and a buffer of nothing but strays
+    d[60::61] = 0x0A
+    acc.zero_()
+    fasta_ms = timed_queued(torch, lambda: cn.n_to_bits_checked_dev(d, out=out, acc=acc), 2, queue, warm=1)
+    fasta_ok = int(acc.item()) == (2 * queue + 1) * len(range(60, n, 61))
+    d.fill_(0x4E)
+    all_ms = timed_queued(torch, lambda: cn.n_to_bits_checked_dev(d, out=out, acc=acc), 2, queue, warm=1)
+    devutil.fill_random_acgt(d, seed + 7)
+    rows["checked_encode"]["dirty_input"] = {
+        "a_line_feed_every_61st_byte": {"ms": stats_ms(fasta_ms), "over_clean": round(statistics.median(fasta_ms) / med_c, 3), "count_exact": bool(fasta_ok)},
+        "every_byte_a_stray": {"ms": stats_ms(all_ms), "over_clean": round(statistics.median(all_ms) / med_c, 3)},
+        "what": "one no-return atomic per 2-KiB tile on ONE device counter (8.4 M of them at 2^34 nt): what a validated encode costs when the data is not clean"}
+    ok_checked = ok_checked and fasta_ok
     rows["checked_encode"]["verified"] = bool(ok_checked)
     dist = int(po.hamming_dev(x, y, n).item())
     ok = ok_checked and abs(dist / n - 0.75) < 1e-3

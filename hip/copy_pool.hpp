@@ -35,7 +35,8 @@
 // memcpy with NON-TEMPORAL stores: the destination is not read by a CPU again soon -- the pinned staging ring, which the DMA
 // engine reads next, or an output larger than any cache -- so its lines need neither be fetched for ownership first (a third
 // of a plain copy's memory traffic) nor linger dirty in some core's L3, where the device's reads have to find them.
-// Lab-selectable (CNT_HOST_NT) until the A/B on the GPU box's host says which copies want it (profiles/r06_host_pipeline.md).
+// Lab-selectable (CNT_HOST_NT) and OFF: on the GPU box's host it loses where it matters (1 GiB: 24.1-24.6 ms against 22.3-22.8
+// with plain stores; profiles/r06_host_tier.md 4) -- the ring's lines are read by the DMA engine out of the cache hierarchy fast enough.
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) inline void copy_stream_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
     size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
@@ -155,10 +156,9 @@ class CopyPool {
     // Where the HELPERS run (the caller is never moved).  `domains` = sets of CPUs that share a last-level cache, i.e. on an EPYC
     // one CCD each -- and every CCD reaches memory through a link of its own: four copying threads inside ONE CCD move 59 GB/s
     // together, one thread in each of four CCDs 100 GB/s, eight 152 GB/s (bench/copy_placement_lab.cpp on the GPU box's host,
-    // profiles/r06_host_placement.md).  Left to the scheduler the team landed anywhere in between, per process: the 1-GiB
-    // host-slice calls ran in 22.1 ms or in 25.9 ms.  Helper k is pinned to domain (first + k - 1) mod n: distinct domains as long
-    // as there are enough, starting behind the caller's own.  Empty = wherever the caller's mask lets them (CNT_HOST_NUMA=0).
-    // Takes effect at the next copy() (a running team is stopped and restarts).
+    // profiles/r06_host_tier.md 2; the scheduler's own placement lands at 84-100).  Helper k is pinned to domain
+    // (first + k - 1) mod n: distinct domains as long as there are enough, starting behind the caller's own.  Empty = wherever
+    // the caller's mask lets them (CNT_HOST_NUMA=0).  Takes effect at the next copy() (a running team is stopped and restarts).
     void set_domains(const std::vector<cpu_set_t>& domains, size_t first) {
         bool same = domains.size() == domains_.size() && (domains.empty() || first == first_);
         for (size_t i = 0; same && i < domains.size(); ++i) same = CPU_EQUAL(&domains[i], &domains_[i]) != 0;

@@ -471,13 +471,15 @@ def test_queue_runs_behind_the_callers_streams_without_any_host_sync(L, oracle, 
         # only when the encode is SEEN to finish while the producer is still asleep -- and one of a few fresh queues must get there.
         want0 = oracle.n_to_bits_lut(oracle.fill_random_acgt(sizes[0], seeds[0]))
         raced = 0
-        shifters = []  # streams kept alive so that every attempt's fresh queue lands on another hardware queue than the last one's
-        for attempt in range(8):
-            d_in[0].zero_()
-            d_pk[0].fill_(-1)
-            shifters.append(torch.cuda.Stream(device=dev))
-            torch.cuda.synchronize()
-            with sharding.DevQueue(1) as q2:
+        held = []  # the attempts' queues stay open: every further hipStreamCreate then lands on another hardware queue (torch's own
+        # streams come out of a pool that exists already -- creating more of those shifts nothing)
+        try:
+            for attempt in range(8):
+                d_in[0].zero_()
+                d_pk[0].fill_(-1)
+                torch.cuda.synchronize()
+                q2 = sharding.DevQueue(1)
+                held.append(q2)
                 enc_done = torch.cuda.Event()
                 enc_done.record(consumers[0])  # torch creates the HIP event on first record; the queue re-records it
                 torch.cuda.synchronize()
@@ -490,11 +492,14 @@ def test_queue_runs_behind_the_callers_streams_without_any_host_sync(L, oracle, 
                         overtook = True
                         break
                 q2.wait()
-            torch.cuda.synchronize()
-            if overtook:
-                raced += 1
-                assert not np.array_equal(d_pk[0].cpu().numpy().view(np.uint64), want0), attempt  # it packed the buffer of zeros
-                break
+                torch.cuda.synchronize()
+                if overtook:
+                    raced += 1
+                    assert not np.array_equal(d_pk[0].cpu().numpy().view(np.uint64), want0), attempt  # it packed the buffer of zeros
+                    break
+        finally:
+            for q2 in held:
+                q2.close()
         assert raced, "none of 8 fresh queues ran ahead of the sleeping producer: the control never tested anything"
     assert torch.cuda.current_device() == 0
 

@@ -3,7 +3,7 @@ disassembly -- streaming `nt` loads, write-through `sc0 sc1 nt` stores, `v_perm_
 in the 5-letter packer, no waterfall loops, no scratch, register counts far below the residency caps -- and nothing
 checked it: a compiler bump could reintroduce a waterfall loop and only show up as a few percent on the GPU box.
 hipcc cross-compiles gfx950 without a GPU, so the assembly of the library's one translation unit is regenerated here
-(~5 s), compared with the committed digest (profiles/r05_isa_digest.txt) and checked property by property.  Round 4 also
+(~5 s), compared with the committed digest (profiles/r06_isa_digest.txt) and checked property by property.  Round 4 also
 checks what the PRODUCT code object contains: the default kernels and the any-alignment kernels, none of the lab's."""
 import os
 import sys
@@ -56,7 +56,39 @@ def test_defaults_have_not_moved_since_round_3(isa):
     # round 4 on purpose: reverse complement's second load no longer waits for the first (branch-free funnel); the encode window
     # kernel takes 4-KiB tiles (its read-ahead line is 3 % of the tile's reads instead of 6 %)
     carried_over(isa_digest.DIGEST_R03, isa_digest.DIGEST_R04, whole_blocks=("reverse complement:", "encode, any input phase:"))
-    carried_over(isa_digest.DIGEST_R04, isa_digest.DIGEST, edge_only=("decode:", "decode, any output phase:"))
+    carried_over(isa_digest.DIGEST_R04, isa_digest.DIGEST_R05, edge_only=("decode:", "decode, any output phase:"))
+    # round 6 ADDED kernels (the validated twins) and split the encoders' bodies into shared templates: not one line of round 5's
+    # digest moved -- the unflagged kernels are instruction for instruction what they were (VERDICT r05 next-1 "Done")
+    carried_over(isa_digest.DIGEST_R05, isa_digest.DIGEST)
+
+
+def test_validated_twins_are_the_same_tiles_with_a_tail_behind_the_stores(isa):
+    """cnt_*_checked_dev: up to its last store a validated kernel is its unchecked twin (same loads in flight, same policies, same
+    arithmetic); behind the stores sits the suspicion sum -- v_sad_u8, one per input dword -- ONE wave-uniform branch, and only
+    behind that the exact recount and the wave's single atomic."""
+    isa_digest, found = isa
+    for plain, checked, dwords in (("void cnt::n_to_bits_stream<64, 2, 1, 2, 19, false>", "void cnt::n_to_bits_stream_checked<64, 2, 1, 2, 19, false>", 8),
+                                   ("void cnt::n_to_bits_window<4, 1, 2, 19, false>", "void cnt::n_to_bits_window_checked<4, 1, 2, 19, false>", 20),
+                                   ("void cnt::round_trip_stream<64, 4, 1, 2, 19, false>", "void cnt::round_trip_stream_checked<64, 4, 1, 2, 19, false>", 16),
+                                   ("void cnt::round_trip_window<1, 2, 19, false>", "void cnt::round_trip_window_checked<1, 2, 19, false>", 20),
+                                   ("void cnt::n_to_bits2_wave<1, 2, 2, 16, false, 1>", "void cnt::n_to_bits2_wave_checked<2, 2, 16, false, 1>", 16),
+                                   ("void cnt::n_to_bits2_window<2, 16, false, 1>", "void cnt::n_to_bits2_window_checked<2, 16, false, 1>", 16)):
+        tp, _, mp = _tile(isa_digest, found, plain)
+        tc, wc, mc = _tile(isa_digest, found, checked)
+        for key in ("buffer_load_dwordx4", "buffer_store_dword", "buffer_store_dwordx4", "buffer_store_dwordx2", "v_mul_lo_u32", "v_dot4_u32_u8", "v_alignbit_b32", "ds_read"):
+            assert tc["counts"].get(key, 0) == tp["counts"].get(key, 0), (checked, key)
+        assert tc["load_policies"] == tp["load_policies"] and tc["store_policies"] == tp["store_policies"]
+        assert tc["loads_before_first_wait"] == tc["loads"] == tp["loads"]
+        assert abs(tc["instructions"] - tp["instructions"]) <= 6, (checked, tc["instructions"], tp["instructions"])  # the tile is not longer for being checked
+        assert "v_sad_u8" not in tc["counts"] and wc["counts"]["v_sad_u8"] == dwords, (checked, wc["counts"].get("v_sad_u8"))  # behind the stores
+        body = found[checked]["body"]
+        last_store = max(k for k, ins in enumerate(body) if ins.startswith("buffer_store"))
+        first_sad = min(k for k, ins in enumerate(body) if ins.startswith("v_sad_u8"))
+        branch = next(k for k, ins in enumerate(body) if k > first_sad and ins.startswith("s_cbranch"))
+        first_atomic = min(k for k, ins in enumerate(body) if "atomic_add" in ins)
+        assert last_store < first_sad < branch < first_atomic, (checked, last_store, first_sad, branch, first_atomic)
+        assert mc["private_segment_fixed_size"] == 0 and mc["next_free_vgpr"] <= 84
+        assert mc["group_segment_fixed_size"] == mp["group_segment_fixed_size"]
 
 
 def test_product_code_object_holds_no_lab_kernels(isa):
