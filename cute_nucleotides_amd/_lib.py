@@ -19,6 +19,8 @@ HOOKS_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcute_nt_hip_ho
 CNT_OK, CNT_EINVAL, CNT_ECAP, CNT_ELEN, CNT_ENODEV, CNT_ERANGE = 0, 1, 2, 3, 4, 5
 CNT_STRICT_LUT = 0x1
 CNT_TAIL_LUT = 0x4
+CNT_SPREAD_COUNT = 0x8  # the *_checked device entry points: the counter is CNT_COUNT_SLOTS u64, the count their sum
+CNT_COUNT_SLOTS = 2048
 CNT_QUEUE_TIMED = 0x1
 
 _vp, _sz, _u64, _int, _uint = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint

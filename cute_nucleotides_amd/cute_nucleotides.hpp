@@ -228,9 +228,11 @@ inline void n_to_bits_hip_dev(const DeviceBuffer& n, size_t n_len, DeviceBuffer&
 }
 /// Encode + validity count in ONE pass over the resident ASCII (cnt_n_to_bits_checked_dev): the launch ADDS the number of
 /// bytes outside ACGTUacgtu to the u64 at `invalid` (device memory the caller zeroed, e.g. an 8-byte DeviceBuffer).
-inline void n_to_bits_hip_checked_dev(const DeviceBuffer& n, size_t n_len, DeviceBuffer& out, DeviceBuffer& invalid, bool strict_lut = false) {
-    if (n_len > n.size_bytes() || invalid.size_bytes() < 8) throw std::out_of_range("n_to_bits_hip_checked_dev: sizes");
-    detail::check(cnt_n_to_bits_checked_dev(n.data(), n_len, out.data(), out.size_bytes() / 8, strict_lut ? CNT_STRICT_LUT : 0u, invalid.data(), nullptr));
+/// `spread` (CNT_SPREAD_COUNT): `invalid` holds CNT_COUNT_SLOTS u64 (16 KiB) and the count is their sum -- for dirty data.
+inline void n_to_bits_hip_checked_dev(const DeviceBuffer& n, size_t n_len, DeviceBuffer& out, DeviceBuffer& invalid, bool strict_lut = false, bool spread = false) {
+    if (n_len > n.size_bytes() || invalid.size_bytes() < (spread ? 8u * CNT_COUNT_SLOTS : 8u)) throw std::out_of_range("n_to_bits_hip_checked_dev: sizes");
+    detail::check(cnt_n_to_bits_checked_dev(n.data(), n_len, out.data(), out.size_bytes() / 8, (strict_lut ? CNT_STRICT_LUT : 0u) | (spread ? CNT_SPREAD_COUNT : 0u),
+                                            invalid.data(), nullptr));
 }
 /// Enqueue the decode of `len` nucleotides from `words` resident words into `out` (>= len bytes).
 inline void bits_to_n_hip_dev(const DeviceBuffer& bits, size_t words, size_t len, DeviceBuffer& out) {

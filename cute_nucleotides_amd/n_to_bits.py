@@ -197,32 +197,38 @@ def n_to_bits_dev(n, out=None, strict_lut=False, tail_lut=False):
     return out[:words]
 
 
-def _counter(torch, acc, like):
+def _counter(torch, acc, like, slots=1):
     """the device u64 a counting entry point ADDS to: a fresh zeroed scalar, or the caller's (which the CALLER zeroes, so that
-    several calls can accumulate into one counter without a kernel in between)"""
+    several calls can accumulate into one counter without a kernel in between); `slots` of them for the spread form"""
     if acc is None:
-        return torch.zeros(1, dtype=torch.int64, device=like.device)
-    if acc.dtype != torch.int64 or not acc.is_cuda or acc.device != like.device or acc.numel() < 1 or not acc.is_contiguous():
-        raise ValueError("acc must be a contiguous int64 CUDA tensor on the input's device")
+        return torch.zeros(slots, dtype=torch.int64, device=like.device)
+    if acc.dtype != torch.int64 or not acc.is_cuda or acc.device != like.device or acc.numel() < slots or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous int64 CUDA tensor on the input's device with >= %d elements" % slots)
     return acc
 
 
-def n_to_bits_checked_dev(n, out=None, acc=None, strict_lut=False, tail_lut=False):
+def _checked_flags(strict_lut, tail_lut, spread):
+    return encode_flags(strict_lut, tail_lut) | (_lib.CNT_SPREAD_COUNT if spread else 0)
+
+
+def n_to_bits_checked_dev(n, out=None, acc=None, strict_lut=False, tail_lut=False, spread=False):
     """Device-resident encode + validity count in ONE pass (cnt_n_to_bits_checked_dev): returns (words, acc) where acc is a
     device int64 scalar the call ADDED the number of bytes outside ACGTUacgtu to (a fresh zeroed one unless the caller passes
-    its own).  1.25 B/nt of HBM traffic, where validate_dev + n_to_bits_dev is 2.25.  acc.item() synchronises."""
+    its own).  1.25 B/nt of HBM traffic, where validate_dev + n_to_bits_dev is 2.25.  acc.item() synchronises.
+    spread=True (CNT_SPREAD_COUNT): acc has CNT_COUNT_SLOTS = 2048 elements and the count is acc.sum() -- for data in which most
+    tiles hold strays (one atomic per dirty tile on ONE counter is 32 x the clean time at 2^34 nt; over 2048 counters (128 cache lines) it is noise)."""
     torch = _dev_guard(n)
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     words = lib().cnt_words_for(n.numel())
     out = _out_words(torch, out, words, n)
-    acc = _counter(torch, acc, n)
+    acc = _counter(torch, acc, n, _lib.CNT_COUNT_SLOTS if spread else 1)
     _enqueue(n, lib().cnt_n_to_bits_checked_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
-             out.numel(), encode_flags(strict_lut, tail_lut), ctypes.c_void_p(acc.data_ptr()))
+             out.numel(), _checked_flags(strict_lut, tail_lut, spread), ctypes.c_void_p(acc.data_ptr()))
     return out[:words], acc
 
 
-def round_trip_checked_dev(n, out_bits=None, out_n=None, acc=None, strict_lut=False, tail_lut=False):
+def round_trip_checked_dev(n, out_bits=None, out_n=None, acc=None, strict_lut=False, tail_lut=False, spread=False):
     """round_trip_dev + the validity count of n_to_bits_checked_dev, still one pass: (words, canonical ASCII, acc)"""
     torch = _dev_guard(n)
     if n.dtype != torch.uint8:
@@ -230,9 +236,9 @@ def round_trip_checked_dev(n, out_bits=None, out_n=None, acc=None, strict_lut=Fa
     words = lib().cnt_words_for(n.numel())
     out_bits = _out_words(torch, out_bits, words, n)
     out_n = _out_bytes(torch, out_n, n.numel(), n)
-    acc = _counter(torch, acc, n)
+    acc = _counter(torch, acc, n, _lib.CNT_COUNT_SLOTS if spread else 1)
     _enqueue(n, lib().cnt_round_trip_checked_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out_bits.data_ptr()),
-             out_bits.numel(), ctypes.c_void_p(out_n.data_ptr()), encode_flags(strict_lut, tail_lut), ctypes.c_void_p(acc.data_ptr()))
+             out_bits.numel(), ctypes.c_void_p(out_n.data_ptr()), _checked_flags(strict_lut, tail_lut, spread), ctypes.c_void_p(acc.data_ptr()))
     return out_bits[:words], out_n[: n.numel()], acc
 
 

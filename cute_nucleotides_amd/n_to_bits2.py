@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, lib
-from .n_to_bits import _counter, _dev_guard, _enqueue, _out_bytes, _out_words, _own_out, _p, _u8, _u64, encode_flags
+from .n_to_bits import _checked_flags, _counter, _dev_guard, _enqueue, _out_bytes, _out_words, _own_out, _p, _u8, _u64, encode_flags
 
 
 def n_to_bits2_hip(n, strict_lut=False, tail_lut=False):
@@ -93,16 +93,16 @@ def n_to_bits2_dev(n, out=None, strict_lut=False, tail_lut=False):
     return out[:words]
 
 
-def n_to_bits2_checked_dev(n, out=None, acc=None, strict_lut=False, tail_lut=False):
+def n_to_bits2_checked_dev(n, out=None, acc=None, strict_lut=False, tail_lut=False, spread=False):
     """n_to_bits2_dev + the number of bytes outside ACGTUNacgtun added to the device scalar `acc`, one pass: (words, acc)"""
     torch = _dev_guard(n)
     if n.dtype != torch.uint8:
         raise TypeError("nucleotides must be a uint8 tensor")
     words = lib().cnt_words2_for(n.numel())
     out = _out_words(torch, out, words, n)
-    acc = _counter(torch, acc, n)
+    acc = _counter(torch, acc, n, _lib.CNT_COUNT_SLOTS if spread else 1)
     _enqueue(n, lib().cnt_n_to_bits2_checked_dev, ctypes.c_void_p(n.data_ptr()), n.numel(), ctypes.c_void_p(out.data_ptr()),
-             out.numel(), encode_flags(strict_lut, tail_lut), ctypes.c_void_p(acc.data_ptr()))
+             out.numel(), _checked_flags(strict_lut, tail_lut, spread), ctypes.c_void_p(acc.data_ptr()))
     return out[:words], acc
 
 

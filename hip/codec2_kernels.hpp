@@ -196,6 +196,18 @@ __device__ __forceinline__ void wave_sum_to(uint64_t v, unsigned long long* dst)
     }
     if ((threadIdx.x & 63) == 0 && v) (void)__hip_atomic_fetch_add(dst, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Where a checked launch adds: ONE u64 (mask 0), or -- CNT_SPREAD_COUNT -- CNT_COUNT_SLOTS of them, workgroup b adding to slot
+// b & mask.  Atomics on one address serialise at ~12 ns apiece wherever they come from: 2^34 nt in which every 2-KiB tile holds a
+// stray (a FASTA file with its line feeds) is 8.4 M of them = 100 ms against a 3.1-ms encode -- and they serialise per cache LINE,
+// not per address (256 slots = 16 lines: 5.8 ms), hence 2048 slots = 128 lines.
+struct BadCounter {
+    unsigned long long* p = nullptr;
+    uint32_t mask = 0;
+    BadCounter() = default;
+    BadCounter(unsigned long long* q, uint32_t m = 0) : p(q), mask(m) {}
+    explicit operator bool() const { return p != nullptr; }
+    BadCounter slot(int i) const { return BadCounter(p ? p + (size_t)i * (mask + 1) : nullptr, mask); }
+};
 __device__ __forceinline__ void wave_add_invalid(uint32_t bad, unsigned long long* dst) {
     if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) wave_sum_to(bad, dst);
 }
@@ -473,8 +485,8 @@ __global__ __launch_bounds__(BLOCK) void n_to_bits_stream(const uint8_t* __restr
 // CHECKED (round 6; cnt_n_to_bits_checked_dev): the same tile, and *bad += the number of its bytes outside ACGTUacgtu.
 template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void n_to_bits_stream_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                                  uint32_t n_tiles, uint32_t xs, EncodeEdges e, unsigned long long* __restrict__ bad) {
-    n_to_bits_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, true>(in, out, n_tiles, xs, e, bad);
+                                                                  uint32_t n_tiles, uint32_t xs, EncodeEdges e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    n_to_bits_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, true>(in, out, n_tiles, xs, e, bad + (blockIdx.x & slot_mask));
 }
 
 // WINDOW: variant 0's one-wave shape with U loads per lane (U = 4: 4 KiB in, 1 KiB out -- the aligned kernel loses 0.6 % to
@@ -542,8 +554,8 @@ __global__ __launch_bounds__(kWave) void n_to_bits_window(const uint8_t* __restr
 }
 template <int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(kWave) void n_to_bits_window_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n_tiles,
-                                                                  uint32_t phase, uint32_t xs, EncodeEdges e, unsigned long long* __restrict__ bad) {
-    n_to_bits_window_body<U, C, LAUX, SAUX, STRICT, true>(in, out, n_tiles, phase, xs, e, bad);
+                                                                  uint32_t phase, uint32_t xs, EncodeEdges e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    n_to_bits_window_body<U, C, LAUX, SAUX, STRICT, true>(in, out, n_tiles, phase, xs, e, bad + (blockIdx.x & slot_mask));
 }
 
 // FUSED round trip (BASELINE.json configs[3]): one pass that reads the ASCII once and writes BOTH the
@@ -594,8 +606,8 @@ __global__ __launch_bounds__(BLOCK) void round_trip_stream(const uint8_t* __rest
 }
 template <int BLOCK, int U, int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void round_trip_stream_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back,
-                                                                   uint32_t n_tiles, uint32_t xs, RoundTripEdges e, unsigned long long* __restrict__ bad) {
-    round_trip_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, true>(in, packed, back, n_tiles, xs, e, bad);
+                                                                   uint32_t n_tiles, uint32_t xs, RoundTripEdges e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    round_trip_stream_body<BLOCK, U, C, LAUX, SAUX, STRICT, true>(in, packed, back, n_tiles, xs, e, bad + (blockIdx.x & slot_mask));
 }
 
 // FUSED round trip at ANY alignment of its three pointers, still one pass and one launch (round 4).  The tile is laid
@@ -725,8 +737,8 @@ __global__ __launch_bounds__(kWave) void round_trip_window(const uint8_t* __rest
 }
 template <int C, int LAUX, int SAUX, bool STRICT>
 __global__ __launch_bounds__(kWave) void round_trip_window_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, uint8_t* __restrict__ back, uint32_t n_tiles,
-                                                                  uint32_t phase, uint32_t phase2, uint32_t xs, RoundTripEdgesAny e, unsigned long long* __restrict__ bad) {
-    round_trip_window_body<C, LAUX, SAUX, STRICT, true>(in, packed, back, n_tiles, phase, phase2, xs, e, bad);
+                                                                  uint32_t phase, uint32_t phase2, uint32_t xs, RoundTripEdgesAny e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    round_trip_window_body<C, LAUX, SAUX, STRICT, true>(in, packed, back, n_tiles, phase, phase2, xs, e, bad + (blockIdx.x & slot_mask));
 }
 // inputs shorter than a tile + slack: the edge body alone, one launch
 template <bool STRICT>
@@ -734,8 +746,8 @@ __global__ __launch_bounds__(kBlock) void round_trip_generic(RoundTripEdgesAny e
     round_trip_edges_any<STRICT>(e, blockIdx.x * (uint64_t)kBlock + threadIdx.x, (uint64_t)gridDim.x * kBlock);
 }
 template <bool STRICT>
-__global__ __launch_bounds__(kBlock) void round_trip_generic_checked(RoundTripEdgesAny e, unsigned long long* __restrict__ bad) {
-    wave_add_invalid(round_trip_edges_any<STRICT, true>(e, blockIdx.x * (uint64_t)kBlock + threadIdx.x, (uint64_t)gridDim.x * kBlock), bad);
+__global__ __launch_bounds__(kBlock) void round_trip_generic_checked(RoundTripEdgesAny e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    wave_add_invalid(round_trip_edges_any<STRICT, true>(e, blockIdx.x * (uint64_t)kBlock + threadIdx.x, (uint64_t)gridDim.x * kBlock), bad + (blockIdx.x & slot_mask));
 }
 
 // LDS (kept as the measured alternative): each wave loads U x 1 KiB coalesced,
@@ -782,7 +794,8 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_generic(const uint8_t* __res
 
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits_generic_checked(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t* __restrict__ out, uint64_t first_word,
-                                                                    uint64_t n_words, uint64_t lut_from, unsigned long long* __restrict__ bad_out) {
+                                                                    uint64_t n_words, uint64_t lut_from, unsigned long long* __restrict__ bad_out, uint32_t slot_mask) {
+    bad_out += blockIdx.x & slot_mask;
     uint32_t bad = 0;
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock)
         out[w] = encode_word_bytes_checked(n, n_len, w, STRICT || w >= lut_from, bad);
@@ -811,7 +824,8 @@ __global__ __launch_bounds__(kBlock) void n_to_bits_staged(const uint8_t* __rest
 // letter -- so every byte the kernel sees counts
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits_staged_checked(const uint8_t* __restrict__ n, uint64_t* __restrict__ out, uint64_t n_words, uint64_t lut_from,
-                                                                   unsigned long long* __restrict__ bad_out) {
+                                                                   unsigned long long* __restrict__ bad_out, uint32_t slot_mask) {
+    bad_out += blockIdx.x & slot_mask;
     const uint64_t w = blockIdx.x * (uint64_t)kBlock + threadIdx.x;
     uint32_t bad = 0;
     if (w < n_words) {

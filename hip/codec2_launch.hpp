@@ -184,7 +184,7 @@ inline uint32_t edge_groups(uint64_t items, unsigned block, uint64_t n_tiles) {
 // d_n must be 16-B aligned, d_out 4-B (16-B for the lds variant).  Returns 0 / 1 (bad variant).
 // `bad` != nullptr (the *_checked entry points): variant 0's checked twin, *bad += the bytes outside the alphabet.
 template <bool STRICT>
-int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, EncodeEdges e, hipStream_t s, uint64_t* done_nt, unsigned long long* bad = nullptr) {
+int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, EncodeEdges e, hipStream_t s, uint64_t* done_nt, BadCounter bad = BadCounter()) {
     if (bad) variant = 0;  // the lab's other shapes have no checked twin
     if (variant < 0 || variant >= kNumEncodeVariants) return 1;
     const uint64_t tile = kEncodeVariants[variant].tile_nt;
@@ -204,7 +204,7 @@ int launch_encode(int variant, const void* d_n, void* d_out, uint64_t n_len, Enc
 #define CNT_ENC_STREAM(B, U, C, L, S) \
     hipLaunchKernelGGL((n_to_bits_stream<B, U, C, L, S, STRICT>), g, dim3(B), lds, s, in, out, (uint32_t)n_tiles, xs, e)
     if (bad) {
-        hipLaunchKernelGGL((n_to_bits_stream_checked<64, 2, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), g, dim3(64), lds, s, in, out, (uint32_t)n_tiles, xs, e, bad);
+        hipLaunchKernelGGL((n_to_bits_stream_checked<64, 2, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), g, dim3(64), lds, s, in, out, (uint32_t)n_tiles, xs, e, bad.p, bad.mask);
         continue;
     }
     switch (variant) {
@@ -249,7 +249,7 @@ constexpr uint32_t kWindowEncodeTile = 64 * kWindowEncodeU * 16;
 constexpr uint32_t kEncodeStreamTile = 64 * 2 * 16;  // variant 0's tile: what "a whole number of tiles" means for small inputs
 constexpr uint32_t kWindowEncodeSlack = 144;  // bytes a tile may read behind its end
 template <bool STRICT>
-void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s, unsigned long long* bad = nullptr) {
+void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, EncodeEdges e, hipStream_t s, BadCounter bad = BadCounter()) {
     const uint64_t per_launch = max_tiles_per_launch(64);
     const uint32_t lds = std::max(lds_for_cap(12), (kWindowEncodeU + 1) * 256u);  // doubles as the kernel's exchange slab (U + 1 rows of code dwords)
     const uint32_t xs = xcd_shift();
@@ -259,7 +259,7 @@ void launch_encode_window(const uint8_t* base, uint32_t phase, uint8_t* out, uin
         e.groups = first + n_tiles == total_tiles ? edge_groups(encode_edge_items(e), 64, n_tiles) : 0u;
         if (bad)
             hipLaunchKernelGGL((n_to_bits_window_checked<kWindowEncodeU, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
-                               base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e, bad);
+                               base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e, bad.p, bad.mask);
         else
         hipLaunchKernelGGL((n_to_bits_window<kWindowEncodeU, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kWindowEncodeTile, out + first * (kWindowEncodeTile / 4), (uint32_t)n_tiles, phase, xs, e);
@@ -281,7 +281,7 @@ constexpr int kRoundTripDefaultPlan = 3;  // any-alignment launch plan (device_t
 // two of its 2-KiB tiles per 4-KiB unit -- kept selectable (tuning key "round_trip_shape") for A/B runs
 template <bool STRICT>
 void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap, int shape, RoundTripEdges e, hipStream_t s,
-                       unsigned long long* bad = nullptr) {
+                       BadCounter bad = BadCounter()) {
     if (bad) shape = 0;  // the lab's first shape has no checked twin
     // in 4-KiB units: 2^25 - 64 one-wave workgroups per launch, i.e. ONE launch up to (just under) 2^37 nt -- BASELINE.json
     // configs[3] (2^36 nt) included; the lab's shape 1 spends two workgroups per unit
@@ -303,7 +303,7 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
         }
 #endif
         if (bad)
-            hipLaunchKernelGGL((round_trip_stream_checked<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e, bad);
+            hipLaunchKernelGGL((round_trip_stream_checked<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e, bad.p, bad.mask);
         else
         hipLaunchKernelGGL((round_trip_stream<64, 4, 1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s, i0, p0, b0, (uint32_t)n_tiles, xs, e);
     }
@@ -315,7 +315,7 @@ void launch_round_trip(const uint8_t* in, uint8_t* packed, uint8_t* back, uint64
 // Same shape, policies and residency cap as the aligned kernel; the cap's dynamic LDS doubles as the 1280-B exchange slab.
 template <bool STRICT>
 void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2, uint8_t* packed, uint8_t* back, uint64_t total_tiles, uint32_t cap,
-                           RoundTripEdgesAny e, hipStream_t s, int map = 0, unsigned long long* bad = nullptr) {
+                           RoundTripEdgesAny e, hipStream_t s, int map = 0, BadCounter bad = BadCounter()) {
     if (bad) map = 0;
     const uint64_t per_launch = max_tiles_per_launch(64);  // one workgroup per 4-KiB tile under every map: one launch up to 2^37 nt
     const uint32_t lds = std::max(lds_for_cap(cap), kRoundTripAnySlab);
@@ -341,7 +341,7 @@ void launch_round_trip_any(const uint8_t* base, uint32_t phase, uint32_t phase2,
         if (bad)
             hipLaunchKernelGGL((round_trip_window_checked<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                                base + first * kRoundTripAnyTile, packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile,
-                               (uint32_t)n_tiles, phase, phase2, xs, e, bad);
+                               (uint32_t)n_tiles, phase, phase2, xs, e, bad.p, bad.mask);
         else
         hipLaunchKernelGGL((round_trip_window<1, kNT, kSC0 | kSC1 | kNT, STRICT>), dim3(grid_of(n_tiles)), dim3(64), lds, s,
                            base + first * kRoundTripAnyTile, packed + first * (kRoundTripAnyTile / 4), back + first * kRoundTripAnyTile,

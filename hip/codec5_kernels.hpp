@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kBlock) void n_to_bits2_generic(const uint8_t* __re
 
 template <bool STRICT>
 __global__ __launch_bounds__(kBlock) void n_to_bits2_generic_checked(const uint8_t* __restrict__ n, uint64_t n_len, uint64_t* __restrict__ out, uint64_t first_word,
-                                                                     uint64_t n_words, uint64_t lut_from, unsigned long long* __restrict__ bad_out) {
+                                                                     uint64_t n_words, uint64_t lut_from, unsigned long long* __restrict__ bad_out, uint32_t slot_mask) {
+    bad_out += blockIdx.x & slot_mask;
     uint32_t bad = 0;
     for (uint64_t w = first_word + blockIdx.x * (uint64_t)kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock)
         out[w] = encode2_word_bytes_checked(n, n_len, w, STRICT || w >= lut_from, bad);
@@ -403,8 +404,8 @@ __global__ __launch_bounds__(WAVES * 64) void n_to_bits2_wave(const uint8_t* __r
 // CHECKED (round 6; cnt_n_to_bits2_checked_dev): *bad += the tile's bytes outside ACGTUNacgtun
 template <int WPL, int LAUX, int SAUX, bool STRICT, int C = 1>
 __global__ __launch_bounds__(64) void n_to_bits2_wave_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_wave_tiles, uint32_t xs,
-                                                              Encode2Edges e, unsigned long long* __restrict__ bad) {
-    n_to_bits2_wave_body<1, WPL, LAUX, SAUX, STRICT, C, true>(in, out, n_wave_tiles, xs, e, bad);
+                                                              Encode2Edges e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    n_to_bits2_wave_body<1, WPL, LAUX, SAUX, STRICT, C, true>(in, out, n_wave_tiles, xs, e, bad + (blockIdx.x & slot_mask));
 }
 
 // WINDOW: the default shape (one wave, 2 words per lane, 3456 B in, 1 KiB out) for an input at
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(64) void n_to_bits2_window(const uint8_t* __restric
 }
 template <int LAUX, int SAUX, bool STRICT, int C>
 __global__ __launch_bounds__(64) void n_to_bits2_window_checked(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n_wave_tiles, uint32_t phase,
-                                                                uint32_t xs, Encode2Edges e, unsigned long long* __restrict__ bad) {
-    n_to_bits2_window_body<LAUX, SAUX, STRICT, C, true>(in, out, n_wave_tiles, phase, xs, e, bad);
+                                                                uint32_t xs, Encode2Edges e, unsigned long long* __restrict__ bad, uint32_t slot_mask) {
+    n_to_bits2_window_body<LAUX, SAUX, STRICT, C, true>(in, out, n_wave_tiles, phase, xs, e, bad + (blockIdx.x & slot_mask));
 }
 
 // Decode: per round j, lane l loads word j*64+l (8 B, 512 B per wave-instruction), expands

@@ -181,7 +181,7 @@ constexpr int kNumDecode2Variants = sizeof(kDecode2Variants) / sizeof(kDecode2Va
 // (the two multi-wave variants, 2 and 3, leave them to the caller's generic launches).
 template <bool STRICT>
 int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, Encode2Edges e, hipStream_t s, uint64_t* done_words, bool* edges_done,
-                   unsigned long long* bad = nullptr) {
+                   BadCounter bad = BadCounter()) {
     if (bad) variant = 0;  // the checked twin exists for the shipped shape only
     if (variant < 0 || variant >= kNumEncode2Variants) return 1;
     const uint64_t tile_nt = kEncode2Variants[variant].tile_nt, tile_words = tile_nt / 27;
@@ -218,7 +218,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
         }
 #endif
         if (bad) {
-            hipLaunchKernelGGL((n_to_bits2_wave_checked<2, kNT, kSC1, STRICT>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e, bad);
+            hipLaunchKernelGGL((n_to_bits2_wave_checked<2, kNT, kSC1, STRICT>), dim3(grid_of(n)), dim3(64), lds, s, in, out, n, xs, e, bad.p, bad.mask);
             continue;
         }
         switch (variant) {
@@ -256,7 +256,7 @@ int launch_encode2(int variant, const void* d_n, void* d_out, uint64_t n_len, En
 constexpr uint32_t kWindowEncode2Tile = 2 * kWaveBytes5;  // nt per tile (128 words)
 constexpr uint32_t kWindowEncode2Slack = 128;             // bytes a tile may read behind its end
 template <bool STRICT>
-void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, Encode2Edges e, hipStream_t s, unsigned long long* bad = nullptr) {
+void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, uint64_t total_tiles, Encode2Edges e, hipStream_t s, BadCounter bad = BadCounter()) {
     const uint64_t per_launch = max_tiles_per_launch(64) / 4 * 4;
     const uint32_t xs = xcd_shift();
     const uint32_t lds = lds_pad_for_cap(kEncode2Variants[0].wg_cap, kWindowSlabDwords5 * 4u);  // four whole wave rows: 640 B more than variant 0's
@@ -266,7 +266,7 @@ void launch_encode2_window(const uint8_t* base, uint32_t phase, uint8_t* out, ui
         e.groups = first + n == total_tiles ? edge_groups(e.head_words + (e.words - e.tail_first), 64, n) : 0u;
         if (bad)
             hipLaunchKernelGGL((n_to_bits2_window_checked<kNT, kSC1, STRICT, 1>), dim3(grid_of(n)), dim3(64), lds, s,
-                               base + first * kWindowEncode2Tile, out + first * 1024, n, phase, xs, e, bad);
+                               base + first * kWindowEncode2Tile, out + first * 1024, n, phase, xs, e, bad.p, bad.mask);
         else
         hipLaunchKernelGGL((n_to_bits2_window<kNT, kSC1, STRICT, 1>), dim3(grid_of(n)), dim3(64), lds, s,
                            base + first * kWindowEncode2Tile, out + first * 1024, n, phase, xs, e);

@@ -285,8 +285,15 @@ int cnt_bits_to_n2_dev(const void *d_bits, size_t words, size_t len, void *d_out
  *     cnt_n_to_bits2_checked_dev                              ACGTUNacgtun     == cnt_validate_dev(d_n, n_len, CNT_ALLOW_N, ...)
  * whatever the encode flags say about how such bytes are ENCODED.  1.25 B/nt of HBM traffic instead of 2.25 for the validated
  * encode.  Cost on clean data: a byte-wise |letter - expected| sum per tile (v_sad_u8) and one wave-uniform branch behind the
- * tile's stores; a wave that saw anything recounts its registers exactly and issues ONE atomic -- so a buffer in which every
- * 2-KiB tile holds a stray byte (a FASTA file with its line feeds, say) costs one atomic per tile on a single counter. */
+ * tile's stores; a wave that saw anything recounts its registers exactly and issues ONE atomic.  Atomics on one address serialise
+ * (~12 ns apiece): 2^34 nt in which EVERY 2-KiB tile holds a stray (a FASTA file fed in with its line feeds) is 8.4 M of them =
+ * 100 ms where the clean buffer takes 3.1.  A caller who expects such data adds
+ *     CNT_SPREAD_COUNT   d_invalid_count points to CNT_COUNT_SLOTS consecutive u64 (16 KiB = 128 cache lines, zeroed by the
+ *                        caller) instead of one; workgroup b adds to slot b % CNT_COUNT_SLOTS; THE COUNT IS THE SUM OF THE SLOTS
+ * to the flags (atomics serialise per cache line: 256 slots = 16 lines still cost 5.8 ms on that buffer).  Clean data runs the
+ * same with or without the flag.  (Device tier and queue forms; the host tier keeps its own counters.) */
+#define CNT_SPREAD_COUNT 0x8u
+#define CNT_COUNT_SLOTS 2048
 int cnt_n_to_bits_checked_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *d_invalid_count, void *stream);
 int cnt_n_to_bits2_checked_dev(const void *d_n, size_t n_len, void *d_out, size_t out_words, unsigned flags, void *d_invalid_count, void *stream);
 int cnt_round_trip_checked_dev(const void *d_n, size_t n_len, void *d_bits, size_t out_words, void *d_back, unsigned flags, void *d_invalid_count, void *stream);

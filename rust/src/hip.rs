@@ -63,6 +63,10 @@ extern "C" {
 const CNT_STRICT_LUT: c_uint = 1;
 const CNT_TAIL_LUT: c_uint = 4;
 const CNT_QUEUE_TIMED: c_uint = 1;
+/// `*_checked_dev` flag: the counter is `CNT_COUNT_SLOTS` consecutive `u64` (16 KiB, zeroed by the caller) and the count is their
+/// sum -- for data in which most 2-KiB tiles hold a stray (one atomic per dirty tile on ONE counter is 32 x the clean time).
+pub const CNT_SPREAD_COUNT: c_uint = 8;
+pub const CNT_COUNT_SLOTS: usize = 2048;
 
 fn check(status: c_int) {
     if status != 0 {
@@ -393,6 +397,13 @@ pub fn n_to_bits_hip_dev(d_n: &DeviceBuffer, n_len: usize, d_out: &DeviceBuffer)
 pub fn n_to_bits_hip_checked_dev(d_n: &DeviceBuffer, n_len: usize, d_out: &DeviceBuffer, d_invalid: &DeviceBuffer) {
     assert!(n_len <= d_n.bytes && d_invalid.bytes >= 8);
     unsafe { check(cnt_n_to_bits_checked_dev(d_n.ptr, n_len, d_out.ptr, d_out.bytes / 8, 0, d_invalid.ptr, std::ptr::null_mut())) };
+}
+
+/// The same with the count spread over `CNT_COUNT_SLOTS` counters (`d_invalid`: >= 16 KiB, zeroed by the caller; the count is the
+/// sum of its first `CNT_COUNT_SLOTS` words): what to use when the data is expected to be dirty.
+pub fn n_to_bits_hip_checked_dev_spread(d_n: &DeviceBuffer, n_len: usize, d_out: &DeviceBuffer, d_invalid: &DeviceBuffer) {
+    assert!(n_len <= d_n.bytes && d_invalid.bytes >= 8 * CNT_COUNT_SLOTS);
+    unsafe { check(cnt_n_to_bits_checked_dev(d_n.ptr, n_len, d_out.ptr, d_out.bytes / 8, CNT_SPREAD_COUNT, d_invalid.ptr, std::ptr::null_mut())) };
 }
 
 /// Enqueue the decode of `len` nucleotides from `words` device-resident words into `d_out` (>= `len` bytes).

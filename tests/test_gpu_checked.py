@@ -94,6 +94,13 @@ def test_checked_encode_writes_the_unchecked_words_and_counts_what_validate_coun
             assert int(acc.item()) == 2 * want_bad
         got = cn.n_to_bits_checked_dev(d, strict_lut=True)[0].cpu().numpy().view(np.uint64)
         assert np.array_equal(got, oracle.n_to_bits_lut(n)), (n_len, seed)  # n_to_bits_lut itself, on any bytes
+        # CNT_SPREAD_COUNT: 2048 counters, workgroup b adds to slot b % 2048, the count is their sum -- same words, same count
+        w_s, acc_s = cn.n_to_bits_checked_dev(d, spread=True)
+        assert acc_s.numel() == 2048 and int(acc_s.sum().item()) == want_bad and torch.equal(w_s, cn.n_to_bits_dev(d)), (n_len, seed)
+        if n_len >= 65536 and seed != 3:
+            assert int((acc_s != 0).sum().item()) > 1  # ... and it really is spread
+        _, _, acc_r = cn.round_trip_checked_dev(d, spread=True)
+        assert int(acc_r.sum().item()) == want_bad
     with pytest.raises(Exception):
         cn.n_to_bits_checked_dev(d, acc=torch.zeros(1, dtype=torch.int32, device="cuda"))
 
@@ -204,6 +211,7 @@ def test_5letter_checked_encode_counts_against_its_own_alphabet(cn, oracle, torc
                 assert acc.cpu().tolist() == [c for _, c in cases], (n_len, io, oo, mode)
     n = _mixed(1 << 20, 9, five=True)
     d = torch.from_numpy(n).cuda()
+    assert int(cn.n_to_bits2_checked_dev(d, spread=True)[1].sum().item()) == oracle.validate(n, allow_n=True)
     w, acc = cn.n_to_bits2_checked_dev(d, strict_lut=True)
     assert np.array_equal(w.cpu().numpy().view(np.uint64), oracle.n_to_bits2_lut(n)) and int(acc.item()) == oracle.validate(n, allow_n=True)
     assert int(cn.n_to_bits_checked_dev(d)[1].item()) == oracle.validate(n)  # the 2-bit encoder counts the N's too
@@ -287,6 +295,9 @@ def test_checked_argument_errors(cn, torch_cuda):
     assert L.cnt_n_to_bits_checked_dev(p(d), 64, p(o), 2, 0, p(c, 4), None) == _lib.CNT_EINVAL  # ... and 8-byte aligned
     assert L.cnt_n_to_bits_checked_dev(p(d), 64, p(o), 1, 0, p(c), None) == _lib.CNT_ECAP
     assert L.cnt_n_to_bits_checked_dev(p(d), 64, p(o), 2, 0x2, p(c), None) == _lib.CNT_EINVAL  # CNT_ALLOW_N is cnt_validate's flag
+    assert L.cnt_n_to_bits_dev(p(d), 64, p(o), 2, _lib.CNT_SPREAD_COUNT, None) == _lib.CNT_EINVAL  # ... and CNT_SPREAD_COUNT the checked calls'
+    hb = ctypes.c_uint64(0)
+    assert L.cnt_n_to_bits_checked(None, 0, None, 0, _lib.CNT_SPREAD_COUNT, ctypes.byref(hb)) == _lib.CNT_EINVAL  # the host tier keeps its own counters
     assert L.cnt_n_to_bits2_checked_dev(p(d), 54, p(o), 2, 0, None, None) == _lib.CNT_EINVAL
     assert L.cnt_round_trip_checked_dev(p(d), 64, p(o), 2, p(d), 0, p(c), None) == _lib.CNT_EINVAL  # back overlaps n
     assert L.cnt_n_to_bits_checked_dev(None, 0, None, 0, 0, p(c), None) == _lib.CNT_OK  # empty in, nothing added

@@ -514,9 +514,15 @@ def test_queue_ordering_entry_points_error_paths_and_the_timed_op_cap(L, alias):
     two = (ctypes.c_void_p * 2)(st[0].cuda_stream, st[1].cuda_stream)
     assert L.cnt_sharded_dev_open_on_streams(2, None, 0, ctypes.byref(q)) == _lib.CNT_EINVAL
     assert L.cnt_sharded_dev_open_on_streams(2, (ctypes.c_void_p * 2)(st[0].cuda_stream, None), 0, ctypes.byref(q)) == _lib.CNT_EINVAL  # never the legacy default stream
-    assert L.cnt_sharded_dev_open_on_streams(65, two, 0, ctypes.byref(q)) == _lib.CNT_ENODEV
+    assert L.cnt_sharded_dev_open_on_streams(65, two, 0, ctypes.byref(q)) == _lib.CNT_EINVAL  # a queue drives at most 64 shards
     assert L.cnt_sharded_dev_open_on_streams(0, two, 0, ctypes.byref(q)) == _lib.CNT_EINVAL  # the array's length IS ndev: "all devices" means nothing here
     assert L.cnt_sharded_dev_open_on_streams(2, two, 0, ctypes.byref(q)) == 0 and q.value
+    # round 6: the queue ASKED both streams where they live -- created under device 0, they say 0, whatever
+    # their position in the array -- and that is the device it makes current for the shard
+    dev = ctypes.c_int(-1)
+    for k in (0, 1):
+        assert L.cnt_sharded_dev_device(q, k, ctypes.byref(dev)) == 0 and dev.value == st[k].device.index == 0
+    assert L.cnt_sharded_dev_device(q, 2, ctypes.byref(dev)) == _lib.CNT_EINVAL and L.cnt_sharded_dev_device(q, 0, None) == _lib.CNT_EINVAL
     ev = torch.cuda.Event()
     ev.record()
     h = ctypes.c_void_p(ev.cuda_event)
