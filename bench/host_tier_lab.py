@@ -39,7 +39,7 @@ def node_cpus():
     return out
 
 
-def child(sizes, reps, pin_after=None):
+def child(sizes, reps, pin_after=None, data_cpus=None):
     import numpy as np
     import torch  # noqa: F401
 
@@ -59,7 +59,12 @@ def child(sizes, reps, pin_after=None):
     for log2 in sizes:
         m = 1 << log2
         block = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, min(m, 1 << 20), dtype=np.uint8)]
+        if data_cpus:  # the INPUT is first touched from these CPUs (another node than the one the calls are made from)
+            back_to = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {int(c) for c in data_cpus.split(",")})
         n = np.tile(block, m // block.size)  # allocated and first touched here: on the caller's node
+        if data_cpus:
+            os.sched_setaffinity(0, back_to)
         bits = np.empty(m // 32, dtype=np.uint64)
         back = np.empty(m, dtype=np.uint8)
         row = {}
@@ -108,10 +113,12 @@ def pcie_ceiling():
     return out
 
 
-def run_cell(env, cpus, sizes, reps, pin_after=None):
+def run_cell(env, cpus, sizes, reps, pin_after=None, data_cpus=None):
     cmd = [sys.executable, os.path.abspath(__file__), "child", ",".join(map(str, sizes)), str(reps)]
-    if pin_after:
-        cmd.append(",".join(map(str, pin_after)))
+    if pin_after or data_cpus:
+        cmd.append(",".join(map(str, pin_after)) if pin_after else "-")
+    if data_cpus:
+        cmd.append(",".join(map(str, data_cpus)))
     if cpus:
         cmd = ["taskset", "-c", ",".join(map(str, cpus))] + cmd
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
@@ -124,7 +131,8 @@ def run_cell(env, cpus, sizes, reps, pin_after=None):
 def main():
     mode = sys.argv[1]
     if mode == "child":
-        return child([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
+        return child([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None,
+                     sys.argv[5] if len(sys.argv) > 5 else None)
     import torch
 
     from cute_nucleotides_amd import devutil
@@ -158,6 +166,14 @@ def main():
                         env = {"CNT_HOST_NUMA": numa, "CNT_HOST_COPY_THREADS": threads}
                         out = run_cell(env, None, (26, 28, 30), 7, pin_after=cpus)
                         print(json.dumps(dict(out, caller_thread=where, env=env, round=rnd)), flush=True)
+    elif mode == "fardata":
+        # the calling thread next to the GPU, its INPUT on the other socket (BENCH-style: the array was made before the scheduler moved
+        # the thread): do helpers pinned to the GPU's node (remote reads by the whole team) lose against helpers left alone?
+        for rnd in range(3):
+            for numa in ("1", "0"):
+                for where, data in (("input near", None), ("input far", far)):
+                    out = run_cell({"CNT_HOST_NUMA": numa}, None, (20, 26, 30), 5, pin_after=near, data_cpus=data)
+                    print(json.dumps(dict(out, data=where, env={"CNT_HOST_NUMA": numa}, round=rnd)), flush=True)
     elif mode == "history":
         # does the size of the calls a process made BEFORE decide how fast its 1-GiB call runs?  (the staging ring grows on demand)
         for rnd in range(2):
