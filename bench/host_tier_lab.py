@@ -113,6 +113,73 @@ def pcie_ceiling():
     return out
 
 
+def duplex():
+    """What the LINK gives the pipeline's own traffic with no host work at all: 1 GiB one way in 8-MiB pieces and 0.25 GiB the
+    other way in 2-MiB pieces, pinned memory both ends, no kernel, no staging copies.  The host tier's per-GiB time can be no
+    better than these; the one-way pinned-hipMemcpy figure the fractions are quoted against ignores the quarter-size return leg."""
+    import torch
+
+    big, small, pieces = 8 << 20, 2 << 20, 128
+    hb = torch.empty(3 * big, dtype=torch.uint8, pin_memory=True).zero_()
+    hs = torch.empty(3 * small, dtype=torch.uint8, pin_memory=True).zero_()
+    db = torch.empty(3 * big, dtype=torch.uint8, device="cuda")
+    ds = torch.empty(3 * small, dtype=torch.uint8, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    seg = lambda t, size, k: t[(k % 3) * size:(k % 3 + 1) * size]
+
+    def timed(body):
+        for _ in range(2):
+            body()
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            body()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return round(statistics.median(ts), 2)
+
+    def one_way(up):
+        def body():
+            with torch.cuda.stream(streams[0]):
+                for k in range(pieces):
+                    (seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True) if up else seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True))
+        return body
+
+    def two_streams(up_big):
+        def body():
+            for k in range(pieces):
+                with torch.cuda.stream(streams[0]):
+                    (seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True) if up_big else seg(ds, small, k).copy_(seg(hs, small, k), non_blocking=True))
+                with torch.cuda.stream(streams[1]):
+                    (seg(hs, small, k).copy_(seg(ds, small, k), non_blocking=True) if up_big else seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True))
+        return body
+
+    def ring(up_big, nslots):
+        def body():
+            for k in range(pieces):
+                with torch.cuda.stream(streams[k % nslots]):
+                    if up_big:
+                        seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True)
+                        seg(hs, small, k).copy_(seg(ds, small, k), non_blocking=True)
+                    else:
+                        seg(ds, small, k).copy_(seg(hs, small, k), non_blocking=True)
+                        seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True)
+        return body
+
+    out = {"ms_per_GiB": {
+        "1 GiB up alone, 128 pieces, one stream": timed(one_way(True)),
+        "1 GiB down alone, 128 pieces, one stream": timed(one_way(False)),
+        "encode traffic (1 GiB up + 0.25 down), an up stream and a down stream": timed(two_streams(True)),
+        "decode traffic (0.25 GiB up + 1 down), an up stream and a down stream": timed(two_streams(False)),
+        "encode traffic, each slot's stream copies up then down, 3 slots": timed(ring(True, 3)),
+        "decode traffic, each slot's stream copies up then down, 3 slots": timed(ring(False, 3)),
+        "encode traffic, each slot's stream copies up then down, 4 slots": timed(ring(True, 4)),
+        "decode traffic, each slot's stream copies up then down, 4 slots": timed(ring(False, 4)),
+    }}
+    print(json.dumps(out), flush=True)
+
+
 def run_cell(env, cpus, sizes, reps, pin_after=None, data_cpus=None):
     cmd = [sys.executable, os.path.abspath(__file__), "child", ",".join(map(str, sizes)), str(reps)]
     if pin_after or data_cpus:
@@ -133,6 +200,8 @@ def main():
     if mode == "child":
         return child([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None,
                      sys.argv[5] if len(sys.argv) > 5 else None)
+    if mode == "duplex_child":
+        return duplex()
     import torch
 
     from cute_nucleotides_amd import devutil
@@ -144,7 +213,11 @@ def main():
     del torch
     near = nodes.get(gpu_node)
     far = next((v for k, v in sorted(nodes.items()) if k != gpu_node and v), None)
-    if mode == "numa":
+    if mode == "duplex":
+        for _ in range(3):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "duplex_child"], capture_output=True, text=True, timeout=600)
+            print(r.stdout.strip() or json.dumps({"error": r.stderr[-400:]}), flush=True)
+    elif mode == "numa":
         cells = []
         for where, cpus in (("near", near), ("far", far), ("anywhere", None)):
             if where != "anywhere" and not cpus:
@@ -166,6 +239,18 @@ def main():
                         env = {"CNT_HOST_NUMA": numa, "CNT_HOST_COPY_THREADS": threads}
                         out = run_cell(env, None, (26, 28, 30), 7, pin_after=cpus)
                         print(json.dumps(dict(out, caller_thread=where, env=env, round=rnd)), flush=True)
+    elif mode == "threads":
+        for rnd in range(2):
+            for threads in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("2", "3", "4", "5", "6", "8", "12")):
+                out = run_cell({"CNT_HOST_COPY_THREADS": threads}, None, (22, 24, 26, 28, 30), 5)
+                print(json.dumps(dict(out, env={"CNT_HOST_COPY_THREADS": threads}, round=rnd)), flush=True)
+    elif mode == "blocks":
+        for rnd in range(2):
+            for threads in ("4", "6", "8"):
+                for ki in ("1024", "512", "256"):
+                    env = {"CNT_HOST_COPY_THREADS": threads, "CNT_HOST_BLOCK_KI": ki}
+                    out = run_cell(env, None, (24, 26, 28, 30), 5)
+                    print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
     elif mode == "fardata":
         # the calling thread next to the GPU, its INPUT on the other socket (BENCH-style: the array was made before the scheduler moved
         # the thread): do helpers pinned to the GPU's node (remote reads by the whole team) lose against helpers left alone?

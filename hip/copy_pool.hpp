@@ -110,7 +110,7 @@ class CopyPool {
         // blocks a huge page of a fresh output is faulted in by ONE thread instead of being fought over by eight
         // (round 4) copies of up to 1 MiB -- the chunks of mid-size calls, 2^20..2^22 nt -- in 256-KiB blocks: with 1-MiB blocks a
         // 1-MiB copy was ONE block, i.e. one thread (larger copies keep 1-MiB blocks: 256-KiB blocks cost 4-MiB copies 5-12 %)
-        const size_t blk = fresh_pages ? kFreshBlock : bytes <= kSmallCopy ? kSmallBlock : kWarmBlock;
+        const size_t blk = fresh_pages ? kFreshBlock : bytes <= kSmallCopy ? kSmallBlock : warm_block();
         const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
         const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
         // Publication order: the block counter moves to generation g FIRST -- from here on nobody can take a
@@ -198,6 +198,14 @@ class CopyPool {
     static constexpr size_t kMinPar = (size_t)512 << 10, kWarmBlock = (size_t)1 << 20, kFreshBlock = (size_t)2 << 20;
     static constexpr size_t kSmallCopy = (size_t)1 << 20, kSmallBlock = (size_t)256 << 10;
     static constexpr int kSpinUs = 150, kStreakUs = 2000;
+    static size_t warm_block() {  // CNT_HOST_BLOCK_KI: lab knob (bench/host_tier_lab.py blocks)
+        static const size_t v = [] {
+            const char* e = getenv("CNT_HOST_BLOCK_KI");
+            const long ki = e ? atol(e) : 0;
+            return ki >= 64 && ki <= 4096 ? (size_t)ki << 10 : kWarmBlock;
+        }();
+        return v;
+    }
     static void cpu_relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();

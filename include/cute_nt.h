@@ -406,9 +406,10 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                overlapped) kept ALL its streams on one engine and ran every later call 15-20 % slower
  *                                (25.9 instead of 22.1 ms per GiB, deterministically).  CNT_HOST_PREALLOC=0: grow the ring with
  *                                the calls instead of allocating it whole (the warm-up then copies what exists)
- *   CNT_HOST_CHUNK_MI, CNT_HOST_PIECES, CNT_HOST_NT   A/B knobs of the pipeline (chunk size in Mi nt, default 8; minimum
- *                                pieces of a mid-size call, default 4; non-temporal stores for the staging copies / copy-outs,
- *                                default off: measured slower at 1 GiB) -- bench/host_tier_lab.py
+ *   CNT_HOST_CHUNK_MI, CNT_HOST_PIECES, CNT_HOST_NT, CNT_HOST_BLOCK_KI   A/B knobs of the pipeline (chunk size in Mi nt,
+ *                                default 8; minimum pieces of a mid-size call, default 4; non-temporal stores for the staging
+ *                                copies / copy-outs, default off: measured slower at 1 GiB; block size of the team's warm
+ *                                copies in KiB, default 1024: 512 and 256 measured 12-25 % slower) -- bench/host_tier_lab.py
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
