@@ -245,3 +245,90 @@ def test_fused_and_packed_ops_fuzz(oracle, seed):
         assert np.array_equal(po.complement_dev(bits, n_len).cpu().numpy().view(np.uint64), oracle.complement(want, n_len)), (seed, n_len)
         assert np.array_equal(po.reverse_complement_dev(bits, n_len).cpu().numpy().view(np.uint64), oracle.reverse_complement(want, n_len)), (seed, n_len)
         assert int(po.validate_dev(view).item()) == oracle.validate(n), (seed, n_len)
+
+
+def _dirty(rng, alpha, n_len):
+    """valid letters with nothing / a few / many / only arbitrary bytes mixed in"""
+    n = alpha[rng.integers(0, alpha.size, n_len)]
+    kind = int(rng.integers(0, 4))
+    if kind == 1 and n_len:
+        where = rng.integers(0, n_len, int(rng.integers(1, 6)))
+        n[where] = rng.integers(0, 256, where.size, dtype=np.uint8)
+    elif kind == 2:
+        mask = rng.integers(0, 3, n_len) == 0
+        n[mask] = rng.integers(0, 256, int(mask.sum()), dtype=np.uint8)
+    elif kind == 3:
+        n = rng.integers(0, 256, n_len, dtype=np.uint8)
+    return n
+
+
+@pytest.mark.parametrize("seed", range(3 * SEEDS))
+def test_validated_encoders_fuzz(oracle, small_nt, seed):
+    """The one-pass validated encoders (round 6) on random lengths, pointer phases, flag modes and dirt densities, one counter
+    or CNT_SPREAD_COUNT: the words are the unvalidated call's bit for bit (and BYTE_LUT's in strict mode), the count is
+    oracle.validate's, and an accumulator that already holds a number keeps it."""
+    import torch
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import n_to_bits2 as n2
+
+    rng = np.random.default_rng(7000 + seed)
+    alpha = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
+    alpha5 = np.frombuffer(b"ACGTUNacgtun", dtype=np.uint8)
+    for n_len in _lengths(rng, 24):
+        off_in, off_out = int(rng.choice([0, 0, 16, 48, 8, 1, 5, 127])), int(rng.choice([0, 0, 1, 2, 15]))
+        strict = bool(rng.integers(0, 2))
+        tail = not strict and bool(rng.integers(0, 2))
+        spread = bool(rng.integers(0, 2))
+        n = _dirty(rng, alpha, n_len)
+        if tail:
+            n = n & 0x7F
+        buf = torch.zeros(n_len + 192, dtype=torch.uint8, device="cuda")
+        view = buf[off_in : off_in + n_len]
+        view.copy_(torch.from_numpy(n))
+        words = (n_len + 31) // 32
+        obuf = torch.full((words + 20,), -1, dtype=torch.int64, device="cuda")
+        plain = cn.n_to_bits_dev(view, strict_lut=strict, tail_lut=tail).cpu().numpy()
+        seeded = int(rng.integers(0, 1000))
+        acc = None
+        if not spread:
+            acc = torch.full((1,), seeded, dtype=torch.int64, device="cuda")
+        got, acc = cn.n_to_bits_checked_dev(view, out=obuf[off_out:], acc=acc, strict_lut=strict, tail_lut=tail, spread=spread)
+        tag = (seed, n_len, off_in, off_out, strict, tail, spread)
+        assert np.array_equal(got.cpu().numpy(), plain), tag
+        if strict:
+            assert np.array_equal(plain.view(np.uint64), oracle.n_to_bits_lut(n)), tag
+        assert int(acc.sum().item()) - (0 if spread else seeded) == oracle.validate(n), tag
+        o = obuf.cpu().numpy()
+        assert (o[:off_out] == -1).all() and (o[off_out + words :] == -1).all(), tag
+        if n_len == 0:
+            continue
+        # fused: packed words + decoded letters + the count, all three pointers at their own phases
+        bo = int(rng.choice([0, 0, 128, 1, 16, 77]))
+        pbuf = torch.full((words + off_out + 8,), -1, dtype=torch.int64, device="cuda")
+        bbuf = torch.full((n_len + bo + 64,), 0x2A, dtype=torch.uint8, device="cuda")
+        bits, back, acc2 = cn.round_trip_checked_dev(view, out_bits=pbuf[off_out : off_out + words], out_n=bbuf[bo : bo + n_len],
+                                                     strict_lut=strict, tail_lut=tail, spread=spread)
+        assert np.array_equal(bits.cpu().numpy(), plain), tag
+        assert np.array_equal(back.cpu().numpy(), oracle.bits_to_n_lut(plain.view(np.uint64), n_len)), tag
+        assert int(acc2.sum().item()) == oracle.validate(n), tag
+        pb, bb = pbuf.cpu().numpy(), bbuf.cpu().numpy()
+        assert (pb[:off_out] == -1).all() and (pb[off_out + words :] == -1).all() and (bb[:bo] == 0x2A).all() and (bb[bo + n_len :] == 0x2A).all(), tag
+        # 5-letter alphabet
+        n5 = _dirty(rng, alpha5, n_len)
+        if tail:
+            n5 = n5 & 0x7F
+        view.copy_(torch.from_numpy(n5))
+        plain5 = n2.n_to_bits2_dev(view, strict_lut=strict, tail_lut=tail).cpu().numpy()
+        got5, acc5 = n2.n_to_bits2_checked_dev(view, strict_lut=strict, tail_lut=tail, spread=spread)
+        assert np.array_equal(got5.cpu().numpy(), plain5), tag
+        assert int(acc5.sum().item()) == oracle.validate(n5, allow_n=True), tag
+    # host slices: small path, pipeline, several chunks
+    for n_len in [int(rng.choice([1, 27, 4096, 40000, 1 << 20, (1 << 20) + 1, 3 << 20])) + int(rng.integers(0, 40)) for _ in range(4)]:
+        strict = bool(rng.integers(0, 2))
+        n = _dirty(rng, alpha, n_len)
+        w, bad = cn.n_to_bits_hip_checked(n, strict_lut=strict)
+        assert np.array_equal(w, cn.n_to_bits_hip(n, strict_lut=strict)) and bad == oracle.validate(n), (seed, n_len, strict)
+        n5 = _dirty(rng, alpha5, n_len)
+        w5, bad5 = n2.n_to_bits2_hip_checked(n5, strict_lut=strict)
+        assert np.array_equal(w5, n2.n_to_bits2_hip(n5, strict_lut=strict)) and bad5 == oracle.validate(n5, allow_n=True), (seed, n_len, strict)
