@@ -251,6 +251,13 @@ def main():
                     env = {"CNT_HOST_COPY_THREADS": threads, "CNT_HOST_BLOCK_KI": ki}
                     out = run_cell(env, None, (24, 26, 28, 30), 5)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "ramp":
+        # piece sizes ramped up and down (chunk/4, chunk/2, full ..., chunk/2, chunk/4) against equal pieces; the value is the
+        # smallest log2(nt) that is ramped
+        for rnd in range(3):
+            for ramp in ("0", "22", "25"):
+                out = run_cell({"CNT_HOST_RAMP": ramp}, None, (22, 23, 24, 25, 26, 27, 28, 30), 7)
+                print(json.dumps(dict(out, env={"CNT_HOST_RAMP": ramp}, round=rnd)), flush=True)
     elif mode == "fardata":
         # the calling thread next to the GPU, its INPUT on the other socket (BENCH-style: the array was made before the scheduler moved
         # the thread): do helpers pinned to the GPU's node (remote reads by the whole team) lose against helpers left alone?

@@ -114,6 +114,7 @@ TEST_HOOK_SIGNATURES = {
     "cnt_test_advise_output": (_int, [_vp, _sz]),
     "cnt_test_round_trip_plan": (_int, [_u64, _u64, _u64, _u64, _uint, ctypes.POINTER(_u64)]),
     "cnt_test_decode_plan": (_int, [_u64, _u64, _u64, _u64, ctypes.POINTER(_u64)]),
+    "cnt_test_pipeline_pieces": (_int, [_u64, _uint, _uint, ctypes.POINTER(_u64), _int]),
 }
 CNT_QUEUE_MAX_TIMED_OPS = 4096
 

@@ -697,6 +697,15 @@ int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t
     out[6] = p.tiles;
     return CNT_OK;
 }
+int cnt_test_pipeline_pieces(uint64_t total_nt, unsigned unit_nt, unsigned ramp_log2, uint64_t* out, int cap) {
+    if ((unit_nt != 32 && unit_nt != 27) || !out || cap < 1) return -1;
+    const size_t chunk = pipeline_chunk(total_nt, unit_nt, unit_nt == 32 ? kChunkNt : kChunkNt5);
+    Pieces p(total_nt, chunk, (size_t)unit_nt * 8192, ramp_log2 ? (size_t)1 << ramp_log2 : 0);
+    int n = 0;
+    for (size_t m; (m = p.next()) != 0; ++n)
+        if (n < cap) out[n] = m;
+    return n;
+}
 int cnt_test_advise_output(void* out, size_t bytes) {
     if (!out) return CNT_EINVAL;
     advise_huge_output(out, bytes);

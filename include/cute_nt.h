@@ -406,10 +406,12 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                overlapped) kept ALL its streams on one engine and ran every later call 15-20 % slower
  *                                (25.9 instead of 22.1 ms per GiB, deterministically).  CNT_HOST_PREALLOC=0: grow the ring with
  *                                the calls instead of allocating it whole (the warm-up then copies what exists)
- *   CNT_HOST_CHUNK_MI, CNT_HOST_PIECES, CNT_HOST_NT, CNT_HOST_BLOCK_KI   A/B knobs of the pipeline (chunk size in Mi nt,
- *                                default 8; minimum pieces of a mid-size call, default 4; non-temporal stores for the staging
- *                                copies / copy-outs, default off: measured slower at 1 GiB; block size of the team's warm
- *                                copies in KiB, default 1024: 512 and 256 measured 12-25 % slower) -- bench/host_tier_lab.py
+ *   CNT_HOST_CHUNK_MI, CNT_HOST_PIECES, CNT_HOST_NT, CNT_HOST_BLOCK_KI, CNT_HOST_RAMP   A/B knobs of the pipeline (chunk size
+ *                                in Mi nt, default 8; minimum pieces of a mid-size call, default 4; non-temporal stores for the
+ *                                staging copies / copy-outs, default off: measured slower at 1 GiB; block size of the team's
+ *                                warm copies in KiB, default 1024: 512 and 256 measured 12-25 % slower; smallest log2(nt) whose
+ *                                pieces are ramped chunk/4, chunk/2, ..., chunk/2, chunk/4, default 0 = never: measured a wash)
+ *                                -- bench/host_tier_lab.py, profiles/r06_host_tier.md 4
  *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
@@ -460,6 +462,11 @@ int cnt_test_round_trip_plan(uint64_t a_n, uint64_t a_bits, uint64_t a_back, uin
  * stream's bit phase, out[4] = its dword phase against the 128-byte line, out[5] = 1 if the window kernel takes the call
  * (either phase non-zero), out[6] = whole tiles.  out holds 7 entries. */
 int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t cache_nt, uint64_t *out);
+/* The piece sizes (nucleotides) the host tier's pipeline would cut a call of `total_nt` nucleotides into, for the 2-bit
+ * (unit_nt 32) or the 5-letter codec (27), with piece sizes ramped for calls of >= 2^ramp_log2 nt (0 = equal pieces): writes the
+ * first `cap` sizes to out[] and returns the number of pieces (-1: bad arguments).  No device needed
+ * (tests/test_pipeline_pieces.py). */
+int cnt_test_pipeline_pieces(uint64_t total_nt, unsigned unit_nt, unsigned ramp_log2, uint64_t *out, int cap);
 #endif /* CNT_TEST_HOOKS */
 
 #ifdef __cplusplus
