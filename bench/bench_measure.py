@@ -410,10 +410,17 @@ def measure_host_tier(seed):
             cn.bits_to_n_hip_into(bits, m, into_n)
             return 0
 
+        # both sides in PINNED memory (cnt_host_alloc): no staging copy either way, the copy engines use the arrays in place
+        cases = [("n_to_bits_hip reused out", enc_reuse), ("bits_to_n_hip reused out", dec_reuse),
+                 ("n_to_bits_hip_into", enc_into), ("bits_to_n_hip_into", dec_into),
+                 ("n_to_bits_hip fresh out", enc_fresh), ("bits_to_n_hip fresh out", dec_fresh)]
+        # (calls of <= 2^20 nt take the zero-copy small path either way)
+        pin_n, pin_w, pin_back = cn.pinned_empty(m, np.uint8), cn.pinned_empty(words, np.uint64), cn.pinned_empty(m, np.uint8)
+        pin_n[:] = n
+        cases[2:2] = [("n_to_bits_hip pinned in + out", lambda: L.cnt_n_to_bits(p(pin_n), m, p(pin_w), words)),
+                      ("bits_to_n_hip pinned in + out", lambda: L.cnt_bits_to_n(p(pin_w), words, m, p(pin_back)))]
         row = {}
-        for name, fn in (("n_to_bits_hip reused out", enc_reuse), ("bits_to_n_hip reused out", dec_reuse),
-                         ("n_to_bits_hip_into", enc_into), ("bits_to_n_hip_into", dec_into),
-                         ("n_to_bits_hip fresh out", enc_fresh), ("bits_to_n_hip fresh out", dec_fresh)):
+        for name, fn in cases:
             assert fn() == 0
             t0, k = time.perf_counter(), 0
             while True:
@@ -436,6 +443,8 @@ def measure_host_tier(seed):
                 kept.clear()
                 row[name + " us"] = round(dt / reps * 1e6, 2)
         assert np.array_equal(back, n) and np.array_equal(into_n, n) and np.array_equal(into_w, bits)
+        assert np.array_equal(pin_w, bits) and np.array_equal(pin_back, n)
+        del pin_n, pin_w, pin_back
         rows["2^%d" % log2] = row
     rows["placement"] = {"input": host_placement(big), "reused_output": host_placement(back)}
     return rows
@@ -447,7 +456,8 @@ def host_tier_block(torch, seed, cpu_rows, pci_bus_id):
     side, where the buffers lie, and the crossover against one CPU thread of the reference's fastest AVX2 path."""
     rows = measure_host_tier(seed)
     pcie = measure_pcie(torch)
-    names = ("n_to_bits_hip reused out", "bits_to_n_hip reused out", "n_to_bits_hip fresh out", "bits_to_n_hip fresh out")
+    names = ("n_to_bits_hip reused out", "bits_to_n_hip reused out", "n_to_bits_hip pinned in + out", "bits_to_n_hip pinned in + out",
+             "n_to_bits_hip fresh out", "bits_to_n_hip fresh out")
     big = rows["2^%d" % HOST_TIER_LOG2[-1]]
     # encode moves N bytes up and N/4 down (full duplex: the H2D leg bounds it), decode N/4 up and N down (the D2H leg)
     frac = {nm: round(big[nm] / pcie["h2d_GiBs" if nm.startswith("n_to_bits") else "d2h_GiBs"], 4) for nm in names}

@@ -176,6 +176,21 @@ int main(int argc, char** argv) {
             fprintf(stderr, "C-ABI mismatch at 2^%zu\n", log2);
             return 2;
         }
+        // ... and with BOTH sides in pinned memory (PinnedBuffer = cnt_host_alloc): no staging copy either way, the copy engines
+        // use the caller's buffers in place (include/cute_nt.h "pinned caller memory")
+        if (log2 > 20) {
+            n_to_bits::PinnedBuffer<uint8_t> pn(len), pback(len);
+            n_to_bits::PinnedBuffer<uint64_t> pbits(bits.size());
+            memcpy(pn.data(), n.data(), len);
+            snprintf(nm, sizeof nm, "n_to_bits_hip_into/2^%zu (pinned in + out)", log2);
+            bench_function("host-tier", nm, len, [&] { g_sink += n_to_bits::n_to_bits_hip_into(pn.data(), len, pbits.data(), pbits.size()); });
+            snprintf(nm, sizeof nm, "bits_to_n_hip_into/2^%zu (pinned in + out)", log2);
+            bench_function("host-tier", nm, len, [&] { g_sink += n_to_bits::bits_to_n_hip_into(pbits.data(), pbits.size(), len, pback.data()); });
+            if (!n_to_bits::is_pinned(pn.data(), len) || memcmp(pbits.data(), bits.data(), bits.size() * 8) || memcmp(pback.data(), n.data(), len)) {
+                fprintf(stderr, "pinned mismatch at 2^%zu\n", log2);
+                return 2;
+            }
+        }
         // what the Rust wrappers do: Vec::with_capacity = malloc without zeroing, filled by the library, dropped --
         // fresh, never-touched pages on every call (the std::vector rows above also pay a single-threaded zero fill)
         snprintf(nm, sizeof nm, "cnt_n_to_bits/2^%zu (fresh malloc)", log2);

@@ -67,6 +67,17 @@ def child(sizes, reps, pin_after=None, data_cpus=None):
             os.sched_setaffinity(0, back_to)
         bits = np.empty(m // 32, dtype=np.uint64)
         back = np.empty(m, dtype=np.uint8)
+        pin = os.environ.get("CNT_LAB_PINNED", "")  # "in", "out", "both": which of the caller's arrays are pinned (cnt_host_alloc)
+        if pin:
+            from cute_nucleotides_amd import pinned_empty
+
+            if pin in ("in", "both"):
+                src = n
+                n = pinned_empty(m, np.uint8)
+                n[:] = src
+                del src
+            if pin in ("out", "both"):
+                bits, back = pinned_empty(m // 32, np.uint64), pinned_empty(m, np.uint8)
         row = {}
         for name, fn in (("enc", lambda: L.cnt_n_to_bits(p(n), m, p(bits), m // 32)), ("dec", lambda: L.cnt_bits_to_n(p(bits), m // 32, m, p(back)))):
             t0 = time.perf_counter()
@@ -167,7 +178,110 @@ def duplex():
                         seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True)
         return body
 
+    def ring_with_kernel(up_big, nslots):
+        """the tier's real shape: copy up, a kernel over the slot (~ the codec's 5 us), copy down, all on the slot's stream"""
+        def body():
+            for k in range(pieces):
+                with torch.cuda.stream(streams[k % nslots]):
+                    if up_big:
+                        seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True)
+                        seg(ds, small, k).copy_(seg(db, big, k)[:small])
+                        seg(hs, small, k).copy_(seg(ds, small, k), non_blocking=True)
+                    else:
+                        seg(ds, small, k).copy_(seg(hs, small, k), non_blocking=True)
+                        seg(db, big, k)[:small].copy_(seg(ds, small, k))
+                        seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True)
+        return body
+
+    ev_up = [torch.cuda.Event() for _ in range(3)]
+    ev_k = [torch.cuda.Event() for _ in range(3)]
+    ev_down = [torch.cuda.Event() for _ in range(3)]
+
+    def three_streams(up_big):
+        """an up stream that only copies up, a kernel stream, a down stream that only copies down; events hand each slot on, and
+        guard the ring (the up copy of piece k + 3 waits for kernel k, kernel k + 3 for down copy k)"""
+        U, K, D = streams[0], streams[1], streams[2]
+
+        def body():
+            for k in range(pieces):
+                s = k % 3
+                with torch.cuda.stream(U):
+                    if k >= 3:
+                        U.wait_event(ev_k[s])
+                    (seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True) if up_big else seg(ds, small, k).copy_(seg(hs, small, k), non_blocking=True))
+                    ev_up[s].record(U)
+                with torch.cuda.stream(K):
+                    K.wait_event(ev_up[s])
+                    if k >= 3:
+                        K.wait_event(ev_down[s])
+                    (seg(ds, small, k).copy_(seg(db, big, k)[:small]) if up_big else seg(db, big, k)[:small].copy_(seg(ds, small, k)))
+                    ev_k[s].record(K)
+                with torch.cuda.stream(D):
+                    D.wait_event(ev_k[s])
+                    (seg(hs, small, k).copy_(seg(ds, small, k), non_blocking=True) if up_big else seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True))
+                    ev_down[s].record(D)
+        return body
+
+    def two_streams_one_event(up_big, kernel_on_up, npieces, nslots=3):
+        """an up stream and a down stream; the kernel rides on one of them; one event hands a piece from up to down, one guards
+        the ring (the up side of piece k + nslots waits for the down copy of piece k)"""
+        U, D = streams[0], streams[1]
+        eu = [torch.cuda.Event() for _ in range(nslots)]
+        ed = [torch.cuda.Event() for _ in range(nslots)]
+
+        def kernel(k):
+            (seg(ds, small, k).copy_(seg(db, big, k)[:small]) if up_big else seg(db, big, k)[:small].copy_(seg(ds, small, k)))
+
+        def body():
+            for k in range(npieces):
+                s = k % nslots
+                with torch.cuda.stream(U):
+                    if k >= nslots:
+                        U.wait_event(ed[s])
+                    (seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True) if up_big else seg(ds, small, k).copy_(seg(hs, small, k), non_blocking=True))
+                    if kernel_on_up:
+                        kernel(k)
+                    eu[s].record(U)
+                with torch.cuda.stream(D):
+                    D.wait_event(eu[s])
+                    if not kernel_on_up:
+                        kernel(k)
+                    (seg(hs, small, k).copy_(seg(ds, small, k), non_blocking=True) if up_big else seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True))
+                    ed[s].record(D)
+        return body
+
+    if os.environ.get("CNT_LAB_DUPLEX") == "short":
+        # short calls: the fixed part (fill, drain, lockstep of the slot streams) decides; microseconds per call
+        res = {}
+        for npieces in (8, 32, 128):
+            for up_big in (True, False):
+                name = "%s traffic, %d pieces: " % ("encode" if up_big else "decode", npieces)
+                def ring_body(nslots, up_big=up_big, npieces=npieces):
+                    def body():
+                        for k in range(npieces):
+                            with torch.cuda.stream(streams[k % nslots]):
+                                if up_big:
+                                    seg(db, big, k).copy_(seg(hb, big, k), non_blocking=True)
+                                    seg(ds, small, k).copy_(seg(db, big, k)[:small])
+                                    seg(hs, small, k).copy_(seg(ds, small, k), non_blocking=True)
+                                else:
+                                    seg(ds, small, k).copy_(seg(hs, small, k), non_blocking=True)
+                                    seg(db, big, k)[:small].copy_(seg(ds, small, k))
+                                    seg(hb, big, k).copy_(seg(db, big, k), non_blocking=True)
+                    return body
+                res[name + "slot ring, 3 slots"] = round(timed(ring_body(3)) * 1e3, 1)
+                res[name + "slot ring, 2 slots"] = round(timed(ring_body(2)) * 1e3, 1)
+                res[name + "up + down stream, kernel on up"] = round(timed(two_streams_one_event(up_big, True, npieces)) * 1e3, 1)
+                res[name + "up + down stream, kernel on down"] = round(timed(two_streams_one_event(up_big, False, npieces)) * 1e3, 1)
+                res[name + "ideal (large leg at the pinned-memcpy rate)"] = round(npieces * 8 / 1024 / 53.4 * 1e6, 1)
+        print(json.dumps({"us_per_call": res}), flush=True)
+        return
+
     out = {"ms_per_GiB": {
+        "encode traffic, slot ring WITH a kernel between the copies, 3 slots": timed(ring_with_kernel(True, 3)),
+        "decode traffic, slot ring WITH a kernel between the copies, 3 slots": timed(ring_with_kernel(False, 3)),
+        "encode traffic, up stream / kernel stream / down stream + events": timed(three_streams(True)),
+        "decode traffic, up stream / kernel stream / down stream + events": timed(three_streams(False)),
         "1 GiB up alone, 128 pieces, one stream": timed(one_way(True)),
         "1 GiB down alone, 128 pieces, one stream": timed(one_way(False)),
         "encode traffic (1 GiB up + 0.25 down), an up stream and a down stream": timed(two_streams(True)),
@@ -178,6 +292,60 @@ def duplex():
         "decode traffic, each slot's stream copies up then down, 4 slots": timed(ring(False, 4)),
     }}
     print(json.dumps(out), flush=True)
+
+
+def trace():
+    """Where a pipelined call's time goes, stage by stage, from the calling thread's own clock (hooks build: cnt_test_host_trace):
+    per size, the median over calls of the time spent waiting for a slot's stream, copying out, staging and submitting, and the
+    stamps of one call."""
+    import numpy as np
+    import torch  # noqa: F401
+
+    from cute_nucleotides_amd import _lib, build
+
+    build.build_hooks()
+    _lib.use_build("hooks")
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for log2 in (24, 26, 28):
+        m = 1 << log2
+        n = np.tile(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 1 << 20, dtype=np.uint8)], m >> 20)
+        bits = np.empty(m // 32, dtype=np.uint64)
+        back = np.empty(m, dtype=np.uint8)
+        if os.environ.get("CNT_LAB_PINNED"):
+            from cute_nucleotides_amd import pinned_empty
+
+            src, n = n, pinned_empty(m, np.uint8)
+            n[:] = src
+            bits, back = pinned_empty(m // 32, np.uint64), pinned_empty(m, np.uint8)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                L.cnt_host_is_pinned(p(n), m)
+            print(json.dumps({"cnt_host_is_pinned_us": round((time.perf_counter() - t0) * 1e4, 2)}), flush=True)
+        for name, fn in (("enc", lambda: L.cnt_n_to_bits(p(n), m, p(bits), m // 32)), ("dec", lambda: L.cnt_bits_to_n(p(bits), m // 32, m, p(back)))):
+            for _ in range(3):
+                assert fn() == 0
+            calls = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                fn()
+                wall = (time.perf_counter() - t0) * 1e6
+                tags = (ctypes.c_int * 4096)()
+                us = (ctypes.c_double * 4096)()
+                k = L.cnt_test_host_trace(tags, us, 4096)
+                calls.append((wall, [(tags[i], us[i]) for i in range(k)]))
+            calls.sort(key=lambda c: c[0])
+            wall, st = calls[len(calls) // 2]
+            spent = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
+            st = [x for x in st if x[0] <= 4]  # 5 / 6: which sides were pinned, not stamps
+            for (_, a), (tag, b) in zip(st, st[1:]):
+                spent[tag] += b - a
+            print(json.dumps({"log2_nt": log2, "call": name, "wall_us": round(wall, 1), "loop_us": round(st[-1][1], 1),
+                              "before_loop_us": round(wall - st[-1][1], 1),
+                              "waiting_for_slot_us": round(spent[1], 1), "copy_out_us": round(spent[2], 1), "staging_us": round(spent[3], 1),
+                              "submitting_us": round(spent[4], 1), "pieces": sum(1 for t, _ in st if t == 4),
+                              "stamps": [[t, round(u, 1)] for t, u in st][:80]}), flush=True)
 
 
 def run_cell(env, cpus, sizes, reps, pin_after=None, data_cpus=None):
@@ -202,6 +370,18 @@ def main():
                      sys.argv[5] if len(sys.argv) > 5 else None)
     if mode == "duplex_child":
         return duplex()
+    if mode == "trace":
+        return trace()
+    if mode == "traces":  # the same under several settings, one process each
+        for env in ({}, {"CNT_HOST_COPY_THREADS": "6"}, {"CNT_HOST_COPY_THREADS": "8"}, {"CNT_HOST_BLOCK_KI": "512"}, {"CNT_HOST_BLOCK_KI": "2048"},
+                    {"CNT_HOST_NUMA": "0"}, {"CNT_HOST_COPY_THREADS": "2"}):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "trace"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+            for l in r.stdout.splitlines():
+                if l.startswith("{"):
+                    d = json.loads(l)
+                    d.pop("stamps")
+                    print(json.dumps(dict(d, env=env)), flush=True)
+        return
     import torch
 
     from cute_nucleotides_amd import devutil
@@ -251,6 +431,13 @@ def main():
                     env = {"CNT_HOST_COPY_THREADS": threads, "CNT_HOST_BLOCK_KI": ki}
                     out = run_cell(env, None, (24, 26, 28, 30), 5)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "pinned":
+        # the caller's arrays in pinned memory: no staging copy on that side.  "in" pins the encode's letters (and nothing of the
+        # decode), "out" both outputs, "both" everything -- so the decode's packed INPUT is the encode's pinned output
+        for rnd in range(3):
+            for pin in ("", "both", "in", "out"):
+                out = run_cell({"CNT_LAB_PINNED": pin}, None, (21, 22, 24, 26, 28, 30), 7)
+                print(json.dumps(dict(out, pinned=pin or "none", round=rnd)), flush=True)
     elif mode == "ramp":
         # piece sizes ramped up and down (chunk/4, chunk/2, full ..., chunk/2, chunk/4) against equal pieces; the value is the
         # smallest log2(nt) that is ramped

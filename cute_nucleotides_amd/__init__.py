@@ -7,8 +7,9 @@ Layout:  ../hip/          HIP kernels + the C-ABI shim (-> libcute_nt_hip.so, in
          sharding.py      contiguous-chunk partition used by the multi-GPU paths
          build.py         hipcc build of the library
 """
-from .n_to_bits import (bits_to_n_dev, bits_to_n_hip, bits_to_n_hip_into, bits_to_n_hip_sharded, n_to_bits_checked_dev, n_to_bits_dev, n_to_bits_hip,
-                        n_to_bits_hip_checked, n_to_bits_hip_into, n_to_bits_hip_sharded, round_trip_checked_dev, round_trip_dev)
+from .n_to_bits import (bits_to_n_dev, bits_to_n_hip, bits_to_n_hip_into, bits_to_n_hip_sharded, host_registered, is_pinned, n_to_bits_checked_dev,
+                        n_to_bits_dev, n_to_bits_hip, n_to_bits_hip_checked, n_to_bits_hip_into, n_to_bits_hip_sharded, pinned_empty,
+                        round_trip_checked_dev, round_trip_dev)
 from .n_to_bits2 import (bits_to_n2_dev, bits_to_n2_hip, bits_to_n2_hip_into, n_to_bits2_checked_dev, n_to_bits2_dev, n_to_bits2_hip,
                          n_to_bits2_hip_checked, n_to_bits2_hip_into)
 
@@ -17,4 +18,5 @@ __all__ = [
     "n_to_bits_hip_into", "bits_to_n_hip_into", "n_to_bits2_hip_into", "bits_to_n2_hip_into",
     "n_to_bits_dev", "bits_to_n_dev", "round_trip_dev", "n_to_bits2_hip", "bits_to_n2_hip", "n_to_bits2_dev", "bits_to_n2_dev",
     "n_to_bits_hip_checked", "n_to_bits2_hip_checked", "n_to_bits_checked_dev", "n_to_bits2_checked_dev", "round_trip_checked_dev",
+    "pinned_empty", "is_pinned", "host_registered",
 ]

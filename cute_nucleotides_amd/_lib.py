@@ -38,6 +38,11 @@ SIGNATURES = {
     "cnt_device_numa_node": (_int, [_int, ctypes.POINTER(_int)]),
     "cnt_shutdown": (_int, []),
     "cnt_host_tier_info": (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "cnt_host_alloc": (_int, [ctypes.POINTER(ctypes.c_void_p), _sz]),
+    "cnt_host_free": (_int, [_vp]),
+    "cnt_host_register": (_int, [_vp, _sz]),
+    "cnt_host_unregister": (_int, [_vp]),
+    "cnt_host_is_pinned": (_int, [_vp, _sz]),
     "cnt_n_to_bits": (_int, [_vp, _sz, _vp, _sz]),
     "cnt_n_to_bits_ex": (_int, [_vp, _sz, _vp, _sz, _uint]),
     "cnt_n_to_bits_checked": (_int, [_vp, _sz, _vp, _sz, _uint, ctypes.POINTER(_u64)]),
@@ -115,6 +120,7 @@ TEST_HOOK_SIGNATURES = {
     "cnt_test_round_trip_plan": (_int, [_u64, _u64, _u64, _u64, _uint, ctypes.POINTER(_u64)]),
     "cnt_test_decode_plan": (_int, [_u64, _u64, _u64, _u64, ctypes.POINTER(_u64)]),
     "cnt_test_pipeline_pieces": (_int, [_u64, _uint, _uint, ctypes.POINTER(_u64), _int]),
+    "cnt_test_host_trace": (_int, [ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_double), _int]),
 }
 CNT_QUEUE_MAX_TIMED_OPS = 4096
 

@@ -124,6 +124,61 @@ inline void bits_to_n_hip_into(const uint64_t* bits, size_t words, size_t len, V
     detail::check(cnt_bits_to_n(bits, words, len, out.data()));
 }
 
+/// Span forms: the 2-bit codec between buffers the CALLER owns -- the forms that can use PINNED memory (`PinnedBuffer`,
+/// `HostPin`): a side that lies in pinned memory is not staged, the copy engines read / write it in place (include/cute_nt.h
+/// "pinned caller memory").  `out` holds at least cnt_words_for(len) words / `len` bytes; returns the count written.
+inline size_t n_to_bits_hip_into(const uint8_t* n, size_t len, uint64_t* out, size_t out_words, bool strict_lut = false, bool tail_lut = false) {
+    detail::check(cnt_n_to_bits_ex(n, len, out, out_words, (strict_lut ? CNT_STRICT_LUT : 0u) | (tail_lut ? CNT_TAIL_LUT : 0u)));
+    return cnt_words_for(len);
+}
+inline size_t bits_to_n_hip_into(const uint64_t* bits, size_t words, size_t len, uint8_t* out) {
+    if (len > (words << 5)) detail::check(CNT_ELEN);
+    detail::check(cnt_bits_to_n(bits, words, len, out));
+    return len;
+}
+
+/// `count` elements of pinned, device-mapped host memory (cnt_host_alloc; NOT zeroed).  For buffers that live as long as the
+/// pipeline: pinned memory cannot be swapped.
+template <class T>
+class PinnedBuffer {
+   public:
+    explicit PinnedBuffer(size_t count) : count_(count) {
+        void* p = nullptr;
+        detail::check(cnt_host_alloc(&p, count * sizeof(T)));
+        ptr_ = static_cast<T*>(p);
+    }
+    ~PinnedBuffer() { (void)cnt_host_free(ptr_); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    PinnedBuffer(PinnedBuffer&& o) noexcept : ptr_(o.ptr_), count_(o.count_) { o.ptr_ = nullptr, o.count_ = 0; }
+    T* data() { return ptr_; }
+    const T* data() const { return ptr_; }
+    size_t size() const { return count_; }
+    T& operator[](size_t i) { return ptr_[i]; }
+    const T& operator[](size_t i) const { return ptr_[i]; }
+    T* begin() { return ptr_; }
+    T* end() { return ptr_ + count_; }
+
+   private:
+    T* ptr_ = nullptr;
+    size_t count_ = 0;
+};
+
+/// Pins an EXISTING range in place for the guard's lifetime (cnt_host_register: tens of milliseconds per GiB, once).
+class HostPin {
+   public:
+    HostPin(void* p, size_t bytes) : p_(p) { detail::check(cnt_host_register(p, bytes)); }
+    ~HostPin() { (void)cnt_host_unregister(p_); }
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+
+   private:
+    void* p_;
+};
+
+/// would the host tier use [p, p + bytes) in place?
+inline bool is_pinned(const void* p, size_t bytes) { return cnt_host_is_pinned(p, bytes) == 1; }
+
 /// The same, cut into contiguous chunks over `ndev` GPUs (<= 0: all visible), no collective.
 inline Vec<uint64_t> n_to_bits_hip_sharded(const uint8_t* n, size_t len, int ndev = 0) {
     Vec<uint64_t> out(cnt_words_for(len));

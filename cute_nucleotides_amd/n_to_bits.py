@@ -87,6 +87,56 @@ def bits_to_n_hip(bits, length):
     return out
 
 
+class _PinnedBlock:
+    """owner of one cnt_host_alloc allocation; freed when the last array built on it is gone"""
+
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        check(lib().cnt_host_alloc(ctypes.byref(self.ptr), max(1, nbytes)))
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and self.ptr.value:
+            lib().cnt_host_free(self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """np.empty in PINNED host memory (cnt_host_alloc): a host-slice call -- n_to_bits_hip_into / bits_to_n_hip_into and the
+    returning forms' inputs -- whose input and / or output is such an array skips the staging copy on that side, the copy
+    engines use the array in place (include/cute_nt.h "pinned caller memory").  For buffers that live as long as the pipeline:
+    pinned memory cannot be swapped.  A torch tensor made with pin_memory=True (`.numpy()`) is the same thing."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape, dtype=np.int64))
+    block = _PinnedBlock(count * dtype.itemsize)
+    raw = (ctypes.c_uint8 * (count * dtype.itemsize)).from_address(block.ptr.value)
+    raw._cnt_block = block  # the view chain keeps `raw` alive, `raw` keeps the allocation
+    return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape)
+
+
+def is_pinned(a):
+    """would the host tier use this array in place? (cnt_host_is_pinned)"""
+    a = np.asarray(a)
+    return bool(a.flags.c_contiguous and a.nbytes and lib().cnt_host_is_pinned(_p(a), a.nbytes))
+
+
+class host_registered:
+    """`with host_registered(a):` pins an EXISTING contiguous array in place for the block (cnt_host_register / _unregister:
+    tens of milliseconds per GiB, once) -- for a buffer the caller cannot allocate through pinned_empty"""
+
+    def __init__(self, a):
+        if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or not a.nbytes:
+            raise ValueError("host_registered: a non-empty contiguous numpy array")
+        self.a = a
+
+    def __enter__(self):
+        check(lib().cnt_host_register(_p(self.a), self.a.nbytes))
+        return self.a
+
+    def __exit__(self, *exc):
+        check(lib().cnt_host_unregister(_p(self.a)))
+        return False
+
+
 def _own_out(out, dtype, need, what):
     if not isinstance(out, np.ndarray) or out.dtype != dtype or not out.flags.c_contiguous or not out.flags.writeable or out.size < need:
         raise ValueError("%s: out must be a writable contiguous %s array with >= %d elements" % (what, np.dtype(dtype).name, need))

@@ -214,6 +214,49 @@ int cnt_host_tier_info(int* device, int* numa_node, int* helper_cpus, int* stagi
     return CNT_OK;
 }
 
+// ---- pinned caller memory: the host tier's fast lane ----------------------------------------------------------------
+// Nothing here keeps a table: whether a slice is pinned is asked of the runtime at every call (host_range_is_pinned), so a
+// buffer freed or unregistered behind the library's back is simply staged again.
+int cnt_host_alloc(void** p, size_t bytes) {
+    if (!p || !bytes) return CNT_EINVAL;
+    *p = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return CNT_ENODEV;
+    }
+    HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    return CNT_OK;
+}
+int cnt_host_free(void* p) {
+    if (!p) return CNT_OK;
+    HIP_TRY(hipHostFree(p));
+    return CNT_OK;
+}
+int cnt_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return CNT_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return CNT_ENODEV;
+    }
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return CNT_OK;
+}
+int cnt_host_unregister(void* p) {
+    if (!p) return CNT_EINVAL;
+    HIP_TRY(hipHostUnregister(p));
+    return CNT_OK;
+}
+int cnt_host_is_pinned(const void* p, size_t bytes) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return host_range_is_pinned(p, bytes) ? 1 : 0;
+}
+
 static int release_thread_ctx() {
     t_queues.release();
     t_ctx.pool.stop();
@@ -704,6 +747,11 @@ int cnt_test_pipeline_pieces(uint64_t total_nt, unsigned unit_nt, unsigned ramp_
     int n = 0;
     for (size_t m; (m = p.next()) != 0; ++n)
         if (n < cap) out[n] = m;
+    return n;
+}
+int cnt_test_host_trace(int* tags, double* us, int cap) {
+    const int n = (int)t_host_trace.size();
+    for (int i = 0; i < n && i < cap; ++i) tags[i] = t_host_trace[(size_t)i].first, us[i] = t_host_trace[(size_t)i].second;
     return n;
 }
 int cnt_test_advise_output(void* out, size_t bytes) {

@@ -123,6 +123,31 @@ int cnt_bits_to_n2(const uint64_t *bits, size_t words, size_t len, uint8_t *out)
  * not report nodes for that mapping).  The calling thread itself is never moved.  See CNT_HOST_NUMA below. */
 int cnt_host_tier_info(int *device, int *numa_node, int *helper_cpus, int *staging_node);
 
+/* ---- pinned caller memory: the host tier without its staging copies -------------------------------------------------
+ * The host-slice entry points above take ANY memory: they copy the caller's slice into a pinned ring, the copy engines take it
+ * from there, and the result travels back the same way.  Those two host copies -- not the link -- bound the tier (0.75-0.85 of
+ * the pinned-hipMemcpy rate, profiles/r06_host_tier.md).  When a call's input and / or output ALREADY lies in pinned memory,
+ * that side is not staged: the copy engines read `n` / write `out` in place (calls of more than 2^20 nt; smaller ones keep the
+ * zero-copy path).  "Pinned" is asked of the runtime at every call (~1 us) -- hipHostMalloc'ed by anyone (cnt_host_alloc below,
+ * a torch tensor with pin_memory=True, hipHostMalloc in the caller's own code) or registered in place (cnt_host_register,
+ * hipHostRegister); the library keeps no table, so memory freed or unregistered later is simply staged again.  The reference's
+ * signature (&[u8] -> Vec<u64>) allocates per call and cannot use this; the `_into` forms of the mirrors with buffers from
+ * cnt_host_alloc can (rust/src/hip.rs PinnedBuf, cute_nucleotides.hpp PinnedBuffer, cute_nucleotides_amd.pinned_empty).
+ * CNT_HOST_PINNED=0: never look, always stage (A/B).
+ *
+ * cnt_host_alloc      *p = `bytes` of pinned, device-mapped host memory (the runtime places it on the current GPU's NUMA node);
+ *                     usable from every device and every thread; release with cnt_host_free (NULL is fine).  Pinned memory is
+ *                     a scarce resource of the machine (it cannot be swapped): for buffers that live as long as the pipeline.
+ * cnt_host_register   pins [p, p + bytes) of an EXISTING allocation in place (hipHostRegister: tens of milliseconds per GiB,
+ *                     once); cnt_host_unregister(p) before the memory is freed.
+ * cnt_host_is_pinned  1 if the host tier would use [p, p + bytes) in place, else 0 (also 0 without a device).
+ * Errors: CNT_EINVAL (NULL / 0 bytes), CNT_ENODEV, -(hipError_t). */
+int cnt_host_alloc(void **p, size_t bytes);
+int cnt_host_free(void *p);
+int cnt_host_register(void *p, size_t bytes);
+int cnt_host_unregister(void *p);
+int cnt_host_is_pinned(const void *p, size_t bytes);
+
 /* ---- multi-GPU host tier: contiguous-chunk sharding, no collective ------------ */
 /* Same contracts as above; the buffer is cut into `ndev` contiguous chunks on
  * word boundaries (ndev <= 0: all visible devices), one persistent host thread +
@@ -400,6 +425,8 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                per sharded-tier worker) and device: slots x (8 + 8) MiB of pinned host memory and as much
  *                                device scratch (48 + 48 MiB at the default), allocated whole by the thread's first call of
  *                                more than 2^20 nt, released by cnt_shutdown()
+ *   CNT_HOST_PINNED=0            stage pinned caller memory like any other (default: a side of a host-slice call that lies in
+ *                                pinned memory is read / written in place by the copy engines; "pinned caller memory" above)
  *   CNT_HOST_WARM=0              do NOT let the ring's streams make their first copies at allocation time.  The default does:
  *                                the runtime binds a stream to a copy engine when it first copies and takes the engines idle at
  *                                that moment, so a thread whose first pipelined call was a small one (short copies that never
@@ -467,6 +494,10 @@ int cnt_test_decode_plan(uint64_t a_bits, uint64_t a_out, uint64_t len, uint64_t
  * first `cap` sizes to out[] and returns the number of pieces (-1: bad arguments).  No device needed
  * (tests/test_pipeline_pieces.py). */
 int cnt_test_pipeline_pieces(uint64_t total_nt, unsigned unit_nt, unsigned ramp_log2, uint64_t *out, int cap);
+/* The calling thread's last pipelined host-slice call, step by step (lab: bench/host_tier_lab.py trace): tags[i] in 0..4 (0 = the
+ * loop starts, 1 = a slot's stream is idle, 2 = its output is copied out, 3 = the next input is staged, 4 = H2D + kernel + D2H are
+ * submitted) at us[i] microseconds after the first; returns the number of stamps, writes the first `cap`. */
+int cnt_test_host_trace(int *tags, double *us, int cap);
 #endif /* CNT_TEST_HOOKS */
 
 #ifdef __cplusplus

@@ -39,6 +39,12 @@ extern "C" {
     fn cnt_check_device_range(p: *const c_void, bytes: usize, device: c_int) -> c_int;
     fn cnt_set_device(device: c_int) -> c_int;
     fn cnt_shutdown() -> c_int;
+    // pinned caller memory: a side of a host-slice call that lies in it is used in place by the copy engines
+    fn cnt_host_alloc(p: *mut *mut c_void, bytes: usize) -> c_int;
+    fn cnt_host_free(p: *mut c_void) -> c_int;
+    fn cnt_host_register(p: *mut c_void, bytes: usize) -> c_int;
+    fn cnt_host_unregister(p: *mut c_void) -> c_int;
+    fn cnt_host_is_pinned(p: *const c_void, bytes: usize) -> c_int;
     // multi-GPU device tier, enqueue-only: one library stream per shard, any number of ops queued ahead, one wait
     fn cnt_sharded_dev_open(ndev: c_int, flags: c_uint, queue: *mut *mut c_void) -> c_int;
     fn cnt_sharded_dev_open_on_streams(ndev: c_int, streams: *const *mut c_void, flags: c_uint, queue: *mut *mut c_void) -> c_int;
@@ -243,6 +249,93 @@ pub fn bits_to_n2_hip_into(bits: &[u64], len: usize, res: &mut Vec<u8>) {
         check(cnt_bits_to_n2(bits.as_ptr(), bits.len(), len, res.as_mut_ptr()));
         res.set_len(len);
     }
+}
+
+/// Slice forms: the 2-bit codec between slices the CALLER owns -- the forms that can use PINNED memory (`PinnedBuf`, `HostPin`):
+/// a side that lies in pinned memory is not staged, the copy engines read / write it in place (include/cute_nt.h "pinned caller
+/// memory"; 4-10 % at 2^28 nt and above, profiles/r06_host_tier.md).  `n_to_bits_hip_slice` returns the number of words written
+/// (`out` must hold `words_for(n.len())`), `bits_to_n_hip_slice` writes `len` bytes.  Same results, same panics.
+pub fn n_to_bits_hip_slice(n: &[u8], out: &mut [u64]) -> usize {
+    let words = unsafe { cnt_words_for(n.len()) };
+    assert!(out.len() >= words);
+    unsafe { check(cnt_n_to_bits_ex(n.as_ptr(), n.len(), out.as_mut_ptr(), out.len(), 0)) };
+    words
+}
+
+pub fn bits_to_n_hip_slice(bits: &[u64], len: usize, out: &mut [u8]) {
+    if len > (bits.len() << 5) {
+        panic!("The length is greater than the number of nucleotides!");
+    }
+    assert!(out.len() >= len);
+    unsafe { check(cnt_bits_to_n(bits.as_ptr(), bits.len(), len, out.as_mut_ptr())) };
+}
+
+/// `len` elements of pinned, device-mapped host memory (`cnt_host_alloc`), zero-filled; derefs to a slice.  For buffers that
+/// live as long as the pipeline: pinned memory cannot be swapped.
+pub struct PinnedBuf<T: Copy> {
+    ptr: *mut T,
+    len: usize,
+}
+
+impl<T: Copy> PinnedBuf<T> {
+    pub fn new(len: usize) -> PinnedBuf<T> {
+        let bytes = len.checked_mul(std::mem::size_of::<T>()).expect("PinnedBuf: size overflow");
+        assert!(bytes > 0);
+        let mut p: *mut c_void = std::ptr::null_mut();
+        unsafe {
+            check(cnt_host_alloc(&mut p, bytes));
+            std::ptr::write_bytes(p as *mut u8, 0, bytes);
+        }
+        PinnedBuf { ptr: p as *mut T, len }
+    }
+}
+
+impl<T: Copy> std::ops::Deref for PinnedBuf<T> {
+    type Target = [T];
+    fn deref(&self) -> &[T] {
+        unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+
+impl<T: Copy> std::ops::DerefMut for PinnedBuf<T> {
+    fn deref_mut(&mut self) -> &mut [T] {
+        unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+
+impl<T: Copy> Drop for PinnedBuf<T> {
+    fn drop(&mut self) {
+        unsafe { cnt_host_free(self.ptr as *mut c_void) };
+    }
+}
+
+/// Pins an EXISTING slice in place for the guard's lifetime (`cnt_host_register`: tens of milliseconds per GiB, once;
+/// unregistered on drop).  The borrow keeps the memory from being freed or moved while it is pinned.
+pub struct HostPin<'a, T> {
+    slice: &'a mut [T],
+}
+
+impl<'a, T> HostPin<'a, T> {
+    pub fn new(slice: &'a mut [T]) -> HostPin<'a, T> {
+        assert!(!slice.is_empty());
+        unsafe { check(cnt_host_register(slice.as_mut_ptr() as *mut c_void, std::mem::size_of_val(slice))) };
+        HostPin { slice }
+    }
+
+    pub fn get(&mut self) -> &mut [T] {
+        self.slice
+    }
+}
+
+impl<'a, T> Drop for HostPin<'a, T> {
+    fn drop(&mut self) {
+        unsafe { cnt_host_unregister(self.slice.as_mut_ptr() as *mut c_void) };
+    }
+}
+
+/// Would the host tier use this slice in place?
+pub fn is_pinned<T>(s: &[T]) -> bool {
+    unsafe { cnt_host_is_pinned(s.as_ptr() as *const c_void, std::mem::size_of_val(s)) == 1 }
 }
 
 /// Contiguous-chunk sharding over `ndev` GPUs (0 = all visible); no collective.
@@ -613,6 +706,25 @@ mod tests {
         device_sync();
         assert_eq!(d_bits.to_vec::<u64>(1), vec![0xD8D8D8D8D8D8D8D8u64]);
         assert_eq!(d_back.to_vec::<u8>(32), n.to_vec());
+    }
+
+    #[test]
+    fn test_pinned_slices_give_the_same_words() {
+        let mut n: PinnedBuf<u8> = PinnedBuf::new(1 << 22);
+        for (i, b) in n.iter_mut().enumerate() {
+            *b = b"ATCG"[i & 3];
+        }
+        assert!(is_pinned(&n[..]) && !is_pinned(&vec![0u8; 4096][..]));
+        let mut out: PinnedBuf<u64> = PinnedBuf::new(words_for(n.len()));
+        let words = n_to_bits_hip_slice(&n, &mut out);
+        assert_eq!(words, 1 << 17);
+        assert!(out.iter().all(|&w| w == 0xD8D8D8D8D8D8D8D8));
+        let mut back = vec![0u8; n.len()];
+        {
+            let mut pin = HostPin::new(&mut back[..]);
+            bits_to_n_hip_slice(&out, 1 << 22, pin.get());
+        }
+        assert_eq!(&back[..], &n[..]);
     }
 
     #[test]

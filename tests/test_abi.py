@@ -56,7 +56,7 @@ def test_product_exports_no_test_hook():
     from cute_nucleotides_amd import _lib, build
 
     hooks = _declared(hooks=True)
-    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) == ["cnt_test_advise_output", "cnt_test_alias_devices", "cnt_test_decode_plan", "cnt_test_pipeline_pieces", "cnt_test_round_trip_plan"]
+    assert hooks == sorted(_lib.TEST_HOOK_SIGNATURES) == ["cnt_test_advise_output", "cnt_test_alias_devices", "cnt_test_decode_plan", "cnt_test_host_trace", "cnt_test_pipeline_pieces", "cnt_test_round_trip_plan"]
     product = _exported(build.build())
     assert not [n for n in product if n.startswith("cnt_test_")], product
     assert _exported(build.build_hooks()) == sorted(product + hooks)

@@ -71,12 +71,17 @@ def test_binding_keeps_the_reference_signatures_and_is_well_formed():
                 r"pub fn on_devices\(devices: &\[i32\], timed: bool\) -> ShardedDevQueue \{", r"pub fn device\(&self, k: usize\) -> i32 \{",
                 r"pub fn enqueue_n_to_bits_checked\(&mut self,"):
         assert re.search(sig, hip), sig
+    # round 6: slices the caller owns (the forms that can take pinned memory), the pinned allocator and the in-place pin
+    for sig in (r"pub fn n_to_bits_hip_slice\(n: &\[u8\], out: &mut \[u64\]\) -> usize \{", r"pub fn bits_to_n_hip_slice\(bits: &\[u64\], len: usize, out: &mut \[u8\]\) \{",
+                r"pub struct PinnedBuf<T: Copy> \{", r"impl<T: Copy> Drop for PinnedBuf<T> \{", r"pub struct HostPin<'a, T> \{", r"impl<'a, T> Drop for HostPin<'a, T> \{",
+                r"pub fn is_pinned<T>\(s: &\[T\]\) -> bool \{"):
+        assert re.search(sig, hip), sig
     # the reference's panic text wherever a decoder checks `len` (n_to_bits.rs:52-54)
     assert hip.count('panic!("The length is greater than the number of nucleotides!")') >= 6
     # every call of a status-returning C symbol goes through check(...) (the three Drop impls and the bool probe excepted)
     calls = re.findall(r"\b(cnt_\w+)\(", hip.split('extern "C" {', 1)[1].split("}", 1)[1])
     body = hip.split("fn check(status: c_int)", 1)[1]
-    for name in set(calls) - {"cnt_strerror", "cnt_words_for", "cnt_words2_for"}:
+    for name in set(calls) - {"cnt_strerror", "cnt_words_for", "cnt_words2_for", "cnt_host_is_pinned"}:  # the last answers 1 / 0, not a status
         sites = [m.start() for m in re.finditer(r"\b%s\(" % name, body)]
         for s in sites:
             line = body[body.rfind("\n", 0, s) + 1 : body.find("\n", s)]
