@@ -435,9 +435,31 @@ def main():
         # the caller's arrays in pinned memory: no staging copy on that side.  "in" pins the encode's letters (and nothing of the
         # decode), "out" both outputs, "both" everything -- so the decode's packed INPUT is the encode's pinned output
         for rnd in range(3):
-            for pin in ("", "both", "in", "out"):
-                out = run_cell({"CNT_LAB_PINNED": pin}, None, (21, 22, 24, 26, 28, 30), 7)
+            for pin in ((sys.argv[2].split(",") if len(sys.argv) > 2 else ("", "both", "in", "out"))):
+                pin = "" if pin == "none" else pin
+                out = run_cell({"CNT_LAB_PINNED": pin}, None, (21, 22, 24, 25, 26, 27, 28, 30), 7)
                 print(json.dumps(dict(out, pinned=pin or "none", round=rnd)), flush=True)
+    elif mode == "pinned_ramp":
+        # both sides pinned: nothing staggers the three slot streams, they copy in lockstep; do ramped pieces pull them apart?
+        for rnd in range(3):
+            for ramp in ("0", "22"):
+                for slots in ("3", "2"):
+                    env = {"CNT_LAB_PINNED": "both", "CNT_HOST_RAMP": ramp, "CNT_HOST_SLOTS": slots}
+                    out = run_cell(env, None, (22, 24, 25, 26, 27, 28, 30), 7)
+                    print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "slots2":
+        for rnd in range(3):
+            for pin in ("", "both"):
+                for slots in ("3", "4"):
+                    env = {"CNT_HOST_SLOTS": slots, "CNT_LAB_PINNED": pin}
+                    out = run_cell(env, None, (21, 22, 24, 26, 28, 30), 7)
+                    print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "slots":
+        # ordinary memory, 2 against 3 (and 4) slots at the small pipelined sizes
+        for rnd in range(3):
+            for slots in ("3", "2", "4"):
+                out = run_cell({"CNT_HOST_SLOTS": slots}, None, (21, 22, 23, 24, 25, 26, 28), 7)
+                print(json.dumps(dict(out, env={"CNT_HOST_SLOTS": slots}, round=rnd)), flush=True)
     elif mode == "ramp":
         # piece sizes ramped up and down (chunk/4, chunk/2, full ..., chunk/2, chunk/4) against equal pieces; the value is the
         # smallest log2(nt) that is ramped

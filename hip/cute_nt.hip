@@ -50,7 +50,13 @@ using namespace cnt;
 
 namespace {
 
-inline int hip_rc(hipError_t e) { return e == hipSuccess ? CNT_OK : -(int)e; }
+// A failed runtime call leaves its code in the thread's "last error", which the NEXT hipGetLastError() -- the check behind every
+// kernel launch here -- would report as that launch's: a status handed to the caller is cleared from the thread first.
+inline int hip_rc(hipError_t e) {
+    if (e == hipSuccess) return CNT_OK;
+    (void)hipGetLastError();
+    return -(int)e;
+}
 
 #define CNT_TRY(expr)                      \
     do {                                   \
@@ -689,7 +695,10 @@ int cnt_check_device_range(const void* p, size_t bytes, int device) {
     }
     if (a.type == hipMemoryTypeDevice && a.device != device) {
         int peer = 0;  // another device's memory: fine only where peer access is enabled -- the library never enables it
-        if (hipDeviceCanAccessPeer(&peer, device, a.device) != hipSuccess || !peer) return CNT_EINVAL;
+        if (hipDeviceCanAccessPeer(&peer, device, a.device) != hipSuccess || !peer) {
+            (void)hipGetLastError();
+            return CNT_EINVAL;
+        }
     } else if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeHost && a.type != hipMemoryTypeManaged) {
         return CNT_EINVAL;
     }

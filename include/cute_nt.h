@@ -421,9 +421,9 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                twice the team, so up to 2 x team - 1 helper threads exist per calling thread (7 at the
  *                                default).  The helpers spin for up to 150 us after a copy before they go to sleep, i.e.
  *                                for the length of a pipelined call
- *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 3, 2..4).  Footprint per calling thread (and
+ *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 4, 2..4).  Footprint per calling thread (and
  *                                per sharded-tier worker) and device: slots x (8 + 8) MiB of pinned host memory and as much
- *                                device scratch (48 + 48 MiB at the default), allocated whole by the thread's first call of
+ *                                device scratch (64 + 64 MiB at the default), allocated whole by the thread's first call of
  *                                more than 2^20 nt, released by cnt_shutdown()
  *   CNT_HOST_PINNED=0            stage pinned caller memory like any other (default: a side of a host-slice call that lies in
  *                                pinned memory is read / written in place by the copy engines; "pinned caller memory" above)

@@ -149,3 +149,27 @@ def test_sharded_host_tier_takes_pinned_slices(oracle, hooks_build):
             assert np.array_equal(cn.bits_to_n_hip_sharded(want, n_len - 3, ndev=ndev), oracle.bits_to_n_lut(want, n_len - 3)), ndev
     finally:
         sharding.alias_devices(False)
+
+
+def test_a_failed_runtime_call_does_not_resurface_behind_the_next_launch(oracle):
+    """The runtime keeps a failed call's code as the thread's "last error", and the check behind every kernel launch here reads
+    exactly that: a status the library has handed to its caller (an unregister of memory that was never registered) must not
+    come back as the error of the next, healthy call on an already initialised thread."""
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(15)
+    n = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (1 << 21) + 5)]
+    want = oracle.n_to_bits_lut(n)
+    assert np.array_equal(cn.n_to_bits_hip(n), want)  # streams, ring, chip info: all set up
+    junk = np.empty(8192, np.uint8)
+    for _ in range(3):
+        assert L.cnt_host_unregister(ctypes.c_void_p(junk.ctypes.data)) < 0
+        assert np.array_equal(cn.n_to_bits_hip(n), want)
+        assert np.array_equal(cn.n_to_bits_hip(n[:40000]), want[:1250])  # the small path's launch check as well
+        assert L.cnt_host_free(ctypes.c_void_p(junk.ctypes.data)) < 0  # not a pinned allocation
+        import torch
+
+        d = torch.from_numpy(n.copy()).cuda()
+        assert np.array_equal(cn.n_to_bits_dev(d).cpu().numpy().view(np.uint64), want)
