@@ -454,6 +454,13 @@ def main():
                     env = {"CNT_HOST_SLOTS": slots, "CNT_LAB_PINNED": pin}
                     out = run_cell(env, None, (21, 22, 24, 26, 28, 30), 7)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "direct_max":
+        # both slices pinned: up to which size is ONE kernel over the link (no copies at all) better than the pipeline?
+        for rnd in range(3):
+            for mx in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "20", "21", "22", "23")):
+                env = {"CNT_LAB_PINNED": "both", "CNT_DIRECT_MAX_NT": str((1 << int(mx)) if mx != "0" else 0)}
+                out = run_cell(env, None, (16, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27), 7)
+                print(json.dumps(dict(out, env=env, direct_max_log2=mx, round=rnd)), flush=True)
     elif mode == "slots":
         # ordinary memory, 2 against 3 (and 4) slots at the small pipelined sizes
         for rnd in range(3):

@@ -127,8 +127,9 @@ int cnt_host_tier_info(int *device, int *numa_node, int *helper_cpus, int *stagi
  * The host-slice entry points above take ANY memory: they copy the caller's slice into a pinned ring, the copy engines take it
  * from there, and the result travels back the same way.  Those two host copies -- not the link -- bound the tier (0.75-0.85 of
  * the pinned-hipMemcpy rate, profiles/r06_host_tier.md).  When a call's input and / or output ALREADY lies in pinned memory,
- * that side is not staged: the copy engines read `n` / write `out` in place (calls of more than 2^20 nt; smaller ones keep the
- * zero-copy path).  "Pinned" is asked of the runtime at every call (~1 us) -- hipHostMalloc'ed by anyone (cnt_host_alloc below,
+ * that side is not staged: the copy engines read `n` / write `out` in place; and with BOTH sides pinned, calls of 2^16 .. 2^25 nt
+ * run as ONE kernel that reads and writes the caller's buffers over the link -- no host copy, no copy engine (2^20 nt: 36 us
+ * instead of 64).  "Pinned" is asked of the runtime at every call (~1 us) -- hipHostMalloc'ed by anyone (cnt_host_alloc below,
  * a torch tensor with pin_memory=True, hipHostMalloc in the caller's own code) or registered in place (cnt_host_register,
  * hipHostRegister); the library keeps no table, so memory freed or unregistered later is simply staged again.  The reference's
  * signature (&[u8] -> Vec<u64>) allocates per call and cannot use this; the `_into` forms of the mirrors with buffers from
@@ -426,7 +427,9 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                device scratch (64 + 64 MiB at the default), allocated whole by the thread's first call of
  *                                more than 2^20 nt, released by cnt_shutdown()
  *   CNT_HOST_PINNED=0            stage pinned caller memory like any other (default: a side of a host-slice call that lies in
- *                                pinned memory is read / written in place by the copy engines; "pinned caller memory" above)
+ *                                pinned memory is read / written in place by the copy engines; "pinned caller memory" above).
+ *                                CNT_DIRECT_MIN_NT / CNT_DIRECT_MAX_NT (2^16 / 2^25): the sizes at which a call with both sides
+ *                                pinned is one kernel over the link instead of a pipeline (A/B)
  *   CNT_HOST_WARM=0              do NOT let the ring's streams make their first copies at allocation time.  The default does:
  *                                the runtime binds a stream to a copy engine when it first copies and takes the engines idle at
  *                                that moment, so a thread whose first pipelined call was a small one (short copies that never

@@ -173,3 +173,53 @@ def test_a_failed_runtime_call_does_not_resurface_behind_the_next_launch(oracle)
 
         d = torch.from_numpy(n.copy()).cuda()
         assert np.array_equal(cn.n_to_bits_dev(d).cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("n_len", [1 << 16, (1 << 16) + 1, 100003, (1 << 18) - 31, 1 << 19, (1 << 20) - 5, 1 << 20])
+def test_small_calls_between_pinned_slices_use_them_in_place(oracle, n_len):
+    """2^16 .. 2^20 nt with both slices pinned: ONE kernel reads and writes the caller's buffers over the link (no memcpy on
+    either side) -- any alignment inside the pinned allocations, every flag mode, both codecs, the validated forms, guards intact"""
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import n_to_bits2 as n2
+
+    rng = np.random.default_rng(n_len)
+    alpha = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
+    alpha5 = np.frombuffer(b"ACGTNacgtnUu", dtype=np.uint8)
+    for off_in, off_out in ((0, 0), (1, 1), (13, 3), (64, 0), (127, 15)):
+        words = (n_len + 31) // 32
+        n = cn.pinned_empty(n_len + off_in + 32, np.uint8)[off_in : off_in + n_len]
+        n[:] = alpha[rng.integers(0, 10, n_len)]
+        whole = cn.pinned_empty(words + off_out + 4, np.uint64)
+        whole[:] = 0x5A5A5A5A5A5A5A5A
+        out = whole[off_out:]
+        for strict, tail in ((False, False), (True, False), (False, True)):
+            got = cn.n_to_bits_hip_into(n, out, strict_lut=strict, tail_lut=tail)
+            assert np.array_equal(got, oracle.n_to_bits_lut(n)), (n_len, off_in, off_out, strict, tail)
+        assert (whole[:off_out] == 0x5A5A5A5A5A5A5A5A).all() and (out[words:] == 0x5A5A5A5A5A5A5A5A).all()
+        want = oracle.n_to_bits_lut(n)
+        length = n_len - int(rng.integers(0, 33))
+        bwhole = cn.pinned_empty(n_len + off_in + 64, np.uint8)
+        bwhole[:] = 0x2A
+        back = bwhole[off_in:]
+        got = cn.bits_to_n_hip_into(out[:words], length, back)
+        assert np.array_equal(got, oracle.bits_to_n_lut(want, length)), (n_len, length, off_in, off_out)
+        assert (bwhole[:off_in] == 0x2A).all() and (back[length:] == 0x2A).all()
+        dirty = n.copy()
+        dirty[rng.integers(0, n_len, 9)] = 0x7F
+        pd = cn.pinned_empty(n_len, np.uint8)
+        pd[:] = dirty
+        # the returning form allocates an ordinary output: staged; the C entry point with a pinned output: in place
+        import ctypes
+
+        from cute_nucleotides_amd import _lib
+
+        bad = ctypes.c_uint64(0)
+        assert _lib.lib().cnt_n_to_bits_checked(ctypes.c_void_p(pd.ctypes.data), n_len, ctypes.c_void_p(out.ctypes.data), words, _lib.CNT_STRICT_LUT, ctypes.byref(bad)) == 0
+        assert bad.value == oracle.validate(dirty) and np.array_equal(out[:words], oracle.n_to_bits_lut(dirty)), (n_len, off_in, off_out)
+        n5 = cn.pinned_empty(n_len + off_in, np.uint8)[off_in:]
+        n5[:] = alpha5[rng.integers(0, 12, n_len)]
+        w5 = cn.pinned_empty((n_len + 26) // 27 + off_out, np.uint64)[off_out:]
+        got5 = n2.n_to_bits2_hip_into(n5, w5)
+        want5 = oracle.n_to_bits2_lut(n5)
+        assert np.array_equal(got5, want5), (n_len, off_in, off_out)
+        assert np.array_equal(n2.bits_to_n2_hip_into(got5, length, back), oracle.bits_to_n2_lut(want5, length)), (n_len, length)
