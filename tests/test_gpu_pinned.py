@@ -112,14 +112,15 @@ def test_trace_shows_which_sides_went_unstaged(oracle, hooks_build):
     from cute_nucleotides_amd import _lib
 
     L = _lib.lib()
-    n_len = 1 << 24
+    n_len = (1 << 25) + 8192  # above the single-kernel lane of calls with both sides pinned (2^25 nt): the pipeline, traced
     rng = np.random.default_rng(13)
     letters = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n_len)]
     for pin_in, pin_out in ((True, True), (True, False), (False, True), (False, False)):
         n = cn.pinned_empty(n_len, np.uint8) if pin_in else np.empty(n_len, np.uint8)
         n[:] = letters
         out = cn.pinned_empty(n_len // 32, np.uint64) if pin_out else np.empty(n_len // 32, np.uint64)
-        assert np.array_equal(cn.n_to_bits_hip_into(n, out), oracle.n_to_bits_lut(letters))
+        want = oracle.n_to_bits_lut(letters)
+        assert np.array_equal(cn.n_to_bits_hip_into(n, out), want)
         tags = (ctypes.c_int * 4096)()
         us = (ctypes.c_double * 4096)()
         k = L.cnt_test_host_trace(tags, us, 4096)
