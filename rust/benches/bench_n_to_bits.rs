@@ -187,6 +187,15 @@ fn bench_large(log2_sizes: &[u32]) {
         group.bench_function(&format!("n_to_bits_hip_into/2^{}", log2), || n_to_bits_hip_into(&n, &mut words_into));
         group.bench_function(&format!("bits_to_n_hip_into/2^{}", log2), || bits_to_n_hip_into(&bits, len, &mut n_into));
         assert!(words_into == bits && n_into == n, "_into mismatch at 2^{}", log2);
+        // ... and between PINNED buffers the caller keeps (PinnedBuf = cnt_host_alloc): no staging copy either way -- one kernel
+        // over the link up to 2^25 nt, the copy engines on the caller's own memory above
+        let mut p_n: PinnedBuf<u8> = PinnedBuf::new(len);
+        p_n.copy_from_slice(&n);
+        let mut p_bits: PinnedBuf<u64> = PinnedBuf::new(bits.len());
+        let mut p_back: PinnedBuf<u8> = PinnedBuf::new(len);
+        group.bench_function(&format!("n_to_bits_hip_slice/2^{} (pinned in + out)", log2), || n_to_bits_hip_slice(&p_n, &mut p_bits));
+        group.bench_function(&format!("bits_to_n_hip_slice/2^{} (pinned in + out)", log2), || bits_to_n_hip_slice(&p_bits, len, &mut p_back));
+        assert!(is_pinned(&p_n[..]) && p_bits[..] == bits[..] && p_back[..] == n[..], "pinned mismatch at 2^{}", log2);
 
         let d_n = DeviceBuffer::from_slice(&n);
         let d_bits = DeviceBuffer::new(bits.len() * 8);
