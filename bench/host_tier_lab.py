@@ -78,6 +78,12 @@ def child(sizes, reps, pin_after=None, data_cpus=None):
                 del src
             if pin in ("out", "both"):
                 bits, back = pinned_empty(m // 32, np.uint64), pinned_empty(m, np.uint8)
+            if pin == "big":  # only the LARGE leg of either direction: the encode's letters (above) and the decode's output
+                src = n
+                n = pinned_empty(m, np.uint8)
+                n[:] = src
+                del src
+                back = pinned_empty(m, np.uint8)
         row = {}
         for name, fn in (("enc", lambda: L.cnt_n_to_bits(p(n), m, p(bits), m // 32)), ("dec", lambda: L.cnt_bits_to_n(p(bits), m // 32, m, p(back)))):
             t0 = time.perf_counter()
@@ -453,6 +459,22 @@ def main():
                 for slots in ("3", "4"):
                     env = {"CNT_HOST_SLOTS": slots, "CNT_LAB_PINNED": pin}
                     out = run_cell(env, None, (21, 22, 24, 26, 28, 30), 7)
+                    print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "big_leg":
+        for rnd in range(3):
+            for ramp in ("default", "0"):
+                env = {"CNT_LAB_PINNED": "big"}
+                if ramp != "default":
+                    env["CNT_HOST_RAMP"] = ramp
+                out = run_cell(env, None, (22, 24, 25, 26, 27, 28, 30), 5)
+                print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "mixed_ramp":
+        # ONE side pinned: does the ramp (and which slot count) help when only the large leg goes unstaged?
+        for rnd in range(2):
+            for pin in ("in", "out"):
+                for ramp, slots in (("0", "4"), ("25", "4"), ("25", "3"), ("0", "3")):
+                    env = {"CNT_LAB_PINNED": pin, "CNT_HOST_RAMP": ramp, "CNT_HOST_SLOTS": slots}
+                    out = run_cell(env, None, (24, 26, 28, 30), 5)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
     elif mode == "direct_max":
         # both slices pinned: up to which size is ONE kernel over the link (no copies at all) better than the pipeline?
