@@ -460,6 +460,13 @@ def main():
                     env = {"CNT_HOST_SLOTS": slots, "CNT_LAB_PINNED": pin}
                     out = run_cell(env, None, (21, 22, 24, 26, 28, 30), 7)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "zerocopy_max":
+        # ordinary memory: up to which size is memcpy + ONE kernel over the link + memcpy better than the four-slot pipeline?
+        for rnd in range(3):
+            for mx in ("20", "21", "22", "23"):
+                env = {"CNT_ZEROCOPY_MAX_NT": str(1 << int(mx))}
+                out = run_cell(env, None, (19, 20, 21, 22, 23), 7)
+                print(json.dumps(dict(out, env=env, zero_copy_max_log2=mx, round=rnd)), flush=True)
     elif mode == "big_leg":
         for rnd in range(3):
             for ramp in ("default", "0"):

@@ -424,8 +424,8 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                for the length of a pipelined call
  *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 4, 2..4).  Footprint per calling thread (and
  *                                per sharded-tier worker) and device: slots x (8 + 8) MiB of pinned host memory and as much
- *                                device scratch (64 + 64 MiB at the default), allocated whole by the thread's first call of
- *                                more than 2^20 nt, released by cnt_shutdown()
+ *                                device scratch (64 + 64 MiB at the default), allocated whole by the thread's first pipelined call
+ *                                (more than 2^21 nt to encode, 2^22 to decode), released by cnt_shutdown()
  *   CNT_HOST_PINNED=0            stage pinned caller memory like any other (default: a side of a host-slice call that lies in
  *                                pinned memory is read / written in place by the copy engines; "pinned caller memory" above).
  *                                CNT_DIRECT_MIN_NT / CNT_DIRECT_MAX_NT (2^16 / 2^25): the sizes at which a call with both sides
@@ -442,7 +442,7 @@ int cnt_check_device_range(const void *p, size_t bytes, int device);
  *                                warm copies in KiB, default 1024: 512 and 256 measured 12-25 % slower; smallest log2(nt) whose
  *                                pieces are ramped chunk/4, chunk/2, ..., chunk/2, chunk/4, default 0 = never: measured a wash)
  *                                -- bench/host_tier_lab.py, profiles/r06_host_tier.md 4
- *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^20, 0 = off)
+ *   CNT_ZEROCOPY_MAX_NT          largest call served by the zero-copy small-call path (default 2^21 nt encode, 2^22 decode; 0 = off)
  *   CNT_HOST_SPIN=0              small calls end in hipStreamSynchronize instead of spinning (<= 200 us) on a
  *                                pinned completion word (the spin occupies the calling CPU for that long)
  *   CNT_HOST_HUGEPAGE=0          do NOT madvise(MADV_HUGEPAGE) any part of an output.  The default advises -- the one thing
