@@ -181,6 +181,27 @@ def test_round_6_entry_points_check_their_arguments_before_any_device_work(L):
     assert L.cnt_chip_cache_nt(count.value + 1, ctypes.byref(nt)) == _lib.CNT_ENODEV
 
 
+def test_pinned_memory_entry_points_without_a_device(L):
+    """argument errors first, then CNT_ENODEV: nothing can be pinned for a device that is not there, nothing is pinned, and
+    freeing nothing is fine (this box has no GPU; tests/test_gpu_pinned.py is the other half)"""
+    from cute_nucleotides_amd import _lib
+
+    buf = np.zeros(8192, dtype=np.uint8)
+    p = ctypes.c_void_p(buf.ctypes.data)
+    q = ctypes.c_void_p(0x1234)
+    assert L.cnt_host_alloc(None, 4096) == _lib.CNT_EINVAL
+    assert L.cnt_host_alloc(ctypes.byref(q), 0) == _lib.CNT_EINVAL
+    assert L.cnt_host_register(None, 4096) == _lib.CNT_EINVAL and L.cnt_host_register(p, 0) == _lib.CNT_EINVAL
+    assert L.cnt_host_unregister(None) == _lib.CNT_EINVAL and L.cnt_host_free(None) == _lib.CNT_OK
+    count = ctypes.c_int(-1)
+    assert L.cnt_device_count(ctypes.byref(count)) == _lib.CNT_OK
+    if count.value == 0:
+        assert L.cnt_host_alloc(ctypes.byref(q), 4096) == _lib.CNT_ENODEV and not q.value
+        assert L.cnt_host_register(p, buf.size) == _lib.CNT_ENODEV
+        assert L.cnt_host_is_pinned(p, buf.size) == 0
+    assert L.cnt_host_is_pinned(None, 16) == 0 and L.cnt_host_is_pinned(p, 0) == 0
+
+
 def test_product_build_has_no_kernel_selection(L):
     """the product library contains the default kernels only and nothing that selects code at
     run time -- every cnt_set_tuning key is CNT_EINVAL, the variant tables hold one entry, the getters answer constants."""
