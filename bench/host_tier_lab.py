@@ -460,6 +460,14 @@ def main():
                     env = {"CNT_HOST_SLOTS": slots, "CNT_LAB_PINNED": pin}
                     out = run_cell(env, None, (21, 22, 24, 26, 28, 30), 7)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "far_slots":
+        # the bench line's unlucky case: the calling thread AND its arrays on the far socket; three against four slots, team 4 / 6
+        for rnd in range(3):
+            for where, cpus in (("far", far), ("near", near)):
+                for slots, threads in ([("4", t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else (("4", "4"), ("3", "4"), ("4", "6"))):
+                    env = {"CNT_HOST_SLOTS": slots, "CNT_HOST_COPY_THREADS": threads}
+                    out = run_cell(env, None, (26, 28, 30), 5, pin_after=cpus)
+                    print(json.dumps(dict(out, caller_thread=where, env=env, round=rnd)), flush=True)
     elif mode == "zerocopy_max":
         # ordinary memory: up to which size is memcpy + ONE kernel over the link + memcpy better than the four-slot pipeline?
         for rnd in range(3):

@@ -29,9 +29,9 @@
 // profiles/r01_host_tier_lab.log: pageable hipMemcpyAsync runs at 43 GB/s only after the runtime
 // has pinned the caller's pages and at 8-14 GB/s on first touch; explicit staging is 20-25 GB/s
 // with one copying thread and ~40 GB/s with four, cold or warm).  A small team of helper threads per calling
-// thread does the staging copies with it; CNT_HOST_COPY_THREADS (default 4, 1 = no helper threads at all) sizes the team
+// thread does the staging copies with it; CNT_HOST_COPY_THREADS (default 6, 1 = no helper threads at all) sizes the team
 // of warm copies, the caller included; copies into fresh pages use twice that team, so a calling thread owns up to
-// 2 x team - 1 helper threads (7 at the default), each spinning for up to 150 us after a copy before it sleeps.
+// 2 x team - 1 helper threads (11 at the default), each spinning for up to 150 us after a copy before it sleeps.
 // memcpy with NON-TEMPORAL stores: the destination is not read by a CPU again soon -- the pinned staging ring, which the DMA
 // engine reads next, or an output larger than any cache -- so its lines need neither be fetched for ownership first (a third
 // of a plain copy's memory traffic) nor linger dirty in some core's L3, where the device's reads have to find them.
@@ -198,6 +198,10 @@ class CopyPool {
     static constexpr size_t kMinPar = (size_t)512 << 10, kWarmBlock = (size_t)1 << 20, kFreshBlock = (size_t)2 << 20;
     static constexpr size_t kSmallCopy = (size_t)1 << 20, kSmallBlock = (size_t)256 << 10;
     static constexpr int kSpinUs = 150, kStreakUs = 2000;
+    // Six since round 6 (four before): with the caller next to the GPU 4, 5, 6 and 8 copy alike; with the caller -- and so its
+    // arrays -- on the other socket every copy crosses the socket link once, and 4 threads do not keep it busy (1-GiB decode 24.1-24.3
+    // ms against 21.4-22.5 with six, 2^28 nt 6.1-6.3 against 5.4-5.7; profiles/r06_host_tier.md 12)
+    static constexpr int kDefaultTeam = 6;
     static size_t warm_block() {  // CNT_HOST_BLOCK_KI: lab knob (bench/host_tier_lab.py blocks)
         static const size_t v = [] {
             const char* e = getenv("CNT_HOST_BLOCK_KI");
@@ -214,7 +218,7 @@ class CopyPool {
     int threads() {
         if (!started_) {
             started_ = true;
-            int t = 4;
+            int t = kDefaultTeam;
             if (const char* e = getenv("CNT_HOST_COPY_THREADS")) t = atoi(e);
             if (limit_ > 0) t = std::min(t, limit_);
             team_ = std::max(1, std::min(t, 16));

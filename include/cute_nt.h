@@ -417,9 +417,9 @@ int cnt_chip_cache_nt(int device, uint64_t *nt);
 int cnt_check_device_range(const void *p, size_t bytes, int device);
 
 /* ---- environment variables the host tiers read (all optional) -------------------
- *   CNT_HOST_COPY_THREADS        staging-copy team per calling thread, the caller included (default 4; 1 = no helper thread
+ *   CNT_HOST_COPY_THREADS        staging-copy team per calling thread, the caller included (default 6; 1 = no helper thread
  *                                is ever created); copy-outs into outputs whose pages do not exist yet (a fresh Vec) use
- *                                twice the team, so up to 2 x team - 1 helper threads exist per calling thread (7 at the
+ *                                twice the team, so up to 2 x team - 1 helper threads exist per calling thread (11 at the
  *                                default).  The helpers spin for up to 150 us after a copy before they go to sleep, i.e.
  *                                for the length of a pipelined call
  *   CNT_HOST_SLOTS               slots of the H2D / kernel / D2H pipeline (default 4, 2..4).  Footprint per calling thread (and

@@ -189,7 +189,7 @@ def test_worker_placement_and_copy_thread_budget(L, oracle, alias, monkeypatch):
             assert 0 <= info["n_cpus"] <= allowed
             if info["numa_node"] < 0:
                 assert info["n_cpus"] == 0  # unknown node -> not pinned
-            assert 1 <= info["copy_threads"] <= max(1, min(4, total // ndev)), info
+            assert 1 <= info["copy_threads"] <= max(1, min(6, total // ndev)), info  # 6 = a calling thread's default team
             used += info["copy_threads"]
         assert used <= max(total, ndev)
     monkeypatch.setenv("CNT_SHARD_NUMA", "0")  # only consulted when a worker (re)binds; results never depend on it
