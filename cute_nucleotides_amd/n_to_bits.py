@@ -96,7 +96,10 @@ class _PinnedBlock:
 
     def __del__(self):
         if getattr(self, "ptr", None) and self.ptr.value:
-            lib().cnt_host_free(self.ptr)
+            try:
+                lib().cnt_host_free(self.ptr)
+            except Exception:  # interpreter shutdown: the library (or ctypes itself) may already be gone; the OS reclaims the pages
+                pass
             self.ptr = ctypes.c_void_p()
 
 
