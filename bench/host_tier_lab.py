@@ -460,6 +460,13 @@ def main():
                     env = {"CNT_HOST_SLOTS": slots, "CNT_LAB_PINNED": pin}
                     out = run_cell(env, None, (21, 22, 24, 26, 28, 30), 7)
                     print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
+    elif mode == "small_blocks":
+        # the SMALL leg's copies (2 MiB per 8-Mi-nt piece) in 256-KiB blocks instead of two 1-MiB ones: more of the team on them
+        for rnd in range(3):
+            for ki in ("1024", "2048", "4096"):
+                env = {"CNT_HOST_SMALL_COPY_KI": ki}
+                out = run_cell(env, None, (22, 24, 26, 28, 30), 5)
+                print(json.dumps(dict(out, env=env, round=rnd)), flush=True)
     elif mode == "far_slots":
         # the bench line's unlucky case: the calling thread AND its arrays on the far socket; three against four slots, team 4 / 6
         for rnd in range(3):

@@ -110,7 +110,7 @@ class CopyPool {
         // blocks a huge page of a fresh output is faulted in by ONE thread instead of being fought over by eight
         // (round 4) copies of up to 1 MiB -- the chunks of mid-size calls, 2^20..2^22 nt -- in 256-KiB blocks: with 1-MiB blocks a
         // 1-MiB copy was ONE block, i.e. one thread (larger copies keep 1-MiB blocks: 256-KiB blocks cost 4-MiB copies 5-12 %)
-        const size_t blk = fresh_pages ? kFreshBlock : bytes <= kSmallCopy ? kSmallBlock : warm_block();
+        const size_t blk = fresh_pages ? kFreshBlock : bytes <= small_block_max() ? kSmallBlock : warm_block();
         const size_t skew = reinterpret_cast<uintptr_t>(dst) & (blk - 1);
         const uint64_t nblocks = (skew + bytes + blk - 1) / blk;
         // Publication order: the block counter moves to generation g FIRST -- from here on nobody can take a
@@ -196,12 +196,23 @@ class CopyPool {
     // per 1-GiB encode); copies into fresh pages in 2-MiB blocks cut on the DESTINATION's 2-MiB grid, so that one thread
     // faults a transparent huge page in instead of eight fighting over it (1-GiB decode into a fresh buffer 35 -> 24 ms).
     static constexpr size_t kMinPar = (size_t)512 << 10, kWarmBlock = (size_t)1 << 20, kFreshBlock = (size_t)2 << 20;
-    static constexpr size_t kSmallCopy = (size_t)1 << 20, kSmallBlock = (size_t)256 << 10;
+    // (round 6) copies of up to 4 MiB -- the SMALL leg of a pipelined piece is 2 MiB: two 1-MiB blocks occupied two of the team --
+    // in 256-KiB blocks: -2...-3 % at 2^26-2^30 nt, -9 % for a 2^22-nt decode (profiles/r06_host_tier.md 13); the 8-MiB copies of the
+    // large leg keep 1-MiB blocks, where smaller ones lose 12-25 % (ibid. 4)
+    static constexpr size_t kSmallCopy = (size_t)1 << 20, kSmallBlock = (size_t)256 << 10, kSmallBlockMax = (size_t)4 << 20;
     static constexpr int kSpinUs = 150, kStreakUs = 2000;
     // Six since round 6 (four before): with the caller next to the GPU 4, 5, 6 and 8 copy alike; with the caller -- and so its
     // arrays -- on the other socket every copy crosses the socket link once, and 4 threads do not keep it busy (1-GiB decode 24.1-24.3
     // ms against 21.4-22.5 with six, 2^28 nt 6.1-6.3 against 5.4-5.7; profiles/r06_host_tier.md 12)
     static constexpr int kDefaultTeam = 6;
+    static size_t small_block_max() {  // CNT_HOST_SMALL_COPY_KI: copies up to this size are cut into 256-KiB blocks (lab knob)
+        static const size_t v = [] {
+            const char* e = getenv("CNT_HOST_SMALL_COPY_KI");
+            const long ki = e ? atol(e) : 0;
+            return ki >= 256 && ki <= 16384 ? (size_t)ki << 10 : kSmallBlockMax;
+        }();
+        return v;
+    }
     static size_t warm_block() {  // CNT_HOST_BLOCK_KI: lab knob (bench/host_tier_lab.py blocks)
         static const size_t v = [] {
             const char* e = getenv("CNT_HOST_BLOCK_KI");
