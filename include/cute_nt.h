@@ -134,6 +134,8 @@ int cnt_host_tier_info(int *device, int *numa_node, int *helper_cpus, int *stagi
  * hipHostRegister); the library keeps no table, so memory freed or unregistered later is simply staged again.  The reference's
  * signature (&[u8] -> Vec<u64>) allocates per call and cannot use this; the `_into` forms of the mirrors with buffers from
  * cnt_host_alloc can (rust/src/hip.rs PinnedBuf, cute_nucleotides.hpp PinnedBuffer, cute_nucleotides_amd.pinned_empty).
+ * The packed-domain host entry points (cnt_hamming, cnt_complement, cnt_reverse_complement, cnt_validate) do the same: with their
+ * slices pinned they run as one kernel over the link instead of copying whole buffers through device scratch.
  * CNT_HOST_PINNED=0: never look, always stage (A/B).
  *
  * cnt_host_alloc      *p = `bytes` of pinned, device-mapped host memory (the runtime places it on the current GPU's NUMA node);

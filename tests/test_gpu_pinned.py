@@ -224,3 +224,43 @@ def test_small_calls_between_pinned_slices_use_them_in_place(oracle, n_len):
         want5 = oracle.n_to_bits2_lut(n5)
         assert np.array_equal(got5, want5), (n_len, off_in, off_out)
         assert np.array_equal(n2.bits_to_n2_hip_into(got5, length, back), oracle.bits_to_n2_lut(want5, length)), (n_len, length)
+
+
+@pytest.mark.parametrize("n_len", [1, 31, 4097, (1 << 16) + 3, (1 << 22) + 77])
+def test_packed_ops_on_pinned_slices(oracle, n_len):
+    """cnt_hamming / cnt_complement / cnt_reverse_complement / cnt_validate with their slices in pinned memory run as one kernel
+    over the link (no copies, no device scratch); same answers as from ordinary memory and as the oracle's definitions; an
+    output that overlaps its input keeps the old path"""
+    import ctypes
+
+    import cute_nucleotides_amd as cn
+    from cute_nucleotides_amd import _lib, packed_ops as po
+
+    L = _lib.lib()
+    rng = np.random.default_rng(77 + n_len)
+    alpha = np.frombuffer(b"ACGTUacgtu", dtype=np.uint8)
+    letters = alpha[rng.integers(0, 10, n_len)]
+    letters2 = alpha[rng.integers(0, 10, n_len)]
+    a, b = oracle.n_to_bits_lut(letters), oracle.n_to_bits_lut(letters2)
+    words = a.size
+    for off in (0, 1, 5):
+        pa = cn.pinned_empty(words + off, np.uint64)[off:]
+        pb = cn.pinned_empty(words + off + 2, np.uint64)[off + 2:]
+        pa[:], pb[:] = a, b
+        assert po.hamming_hip(pa, pb, n_len) == oracle.hamming(a, b, n_len) == po.hamming_hip(a, b, n_len), (n_len, off)
+        out = cn.pinned_empty(words + off + 3, np.uint64)
+        out[:] = 0x5A5A5A5A5A5A5A5A
+        view = out[off : off + words]
+        p = lambda x: ctypes.c_void_p(x.ctypes.data)
+        assert L.cnt_complement(p(pa), n_len, p(view)) == 0
+        assert np.array_equal(view, oracle.complement(a, n_len)), (n_len, off)
+        assert L.cnt_reverse_complement(p(pa), n_len, p(view)) == 0
+        assert np.array_equal(view, oracle.reverse_complement(a, n_len)), (n_len, off)
+        assert (out[:off] == 0x5A5A5A5A5A5A5A5A).all() and (out[off + words :] == 0x5A5A5A5A5A5A5A5A).all()
+        # in place (output == input): the staged path, as always
+        keep = pa.copy()
+        assert L.cnt_complement(p(pa), n_len, p(pa)) == 0 and np.array_equal(pa, oracle.complement(keep, n_len))
+        pn = cn.pinned_empty(n_len + off, np.uint8)[off:]
+        pn[:] = letters
+        pn[rng.integers(0, n_len, 3)] = 0x2D
+        assert po.validate_hip(pn) == oracle.validate(pn) and po.validate_hip(pn, allow_n=True) == oracle.validate(pn, allow_n=True), (n_len, off)
